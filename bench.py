@@ -1,0 +1,168 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mrays/s (whole job) on the RTIOW final scene, 1200x675, 500 spp, depth 50.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" is one full render of the frame: every rank traces its interleaved scanlines with the
+f32 throughput kernel (scene, camera and frame buffers resident in HBM), the resolve kernel packs
+the 8-bit image, and for N > 1 the slabs are all-gathered over RCCL.  A ray is one path segment
+(one closest-hit query over the whole sphere list).  Rank 0 prints one JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+FLOP_PER_TEST = 18.0          # reject-path flops of one ray-sphere test (sphere.rs:29-36, |d|^2 hoisted)
+PEAK_FP32_VALU = 157.3e12     # MI355X vector FP32 peak, FLOP/s
+
+
+def cpu_baseline(spheres, width, depth, seed):
+    """The CPU oracle (a port of the reference's single-threaded loop) timed on a bounded sample."""
+    import _oracle as O
+    cam = O.camera_final(width=width, spp=1, depth=depth)
+    t0 = time.perf_counter()
+    _, _, _, st = O.render(cam, spheres, seed=seed, threads=1)
+    dt = time.perf_counter() - t0
+    one = {"value": st.segments / dt / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "port",
+           "sample": "same scene and camera, %dx%d at 1 spp (%d samples, %d segments, %.1f s), 1 thread as the "
+                     "reference's render loop is single-threaded" % (width, O.image_height(cam), st.samples,
+                                                                    st.segments, dt),
+           "samples_per_s": st.samples / dt}
+    cores = min(16, os.cpu_count() or 1)
+    cam.samples_per_pixel = 2
+    t0 = time.perf_counter()
+    _, _, _, st = O.render(cam, spheres, seed=seed, threads=cores)
+    dt = time.perf_counter() - t0
+    many = {"value": st.segments / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "sample": "same frame at 2 spp, rows in parallel (OpenMP), %.1f s" % dt}
+    return one, many
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--width", type=int, default=1200)
+    ap.add_argument("--spp", type=int, default=500)
+    ap.add_argument("--depth", type=int, default=50)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--mode", default="f32", choices=["f32", "f64", "f32plain"])
+    ap.add_argument("--samples-per-item", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import dray_amd as d
+    from dray_amd import device as ddev
+    from dray_amd import partition
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
+                         % (args.gpus, world, args.gpus))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    spheres = d.scene_final(args.seed)
+    cam = d.camera_final(width=args.width, spp=args.spp, depth=args.depth)
+    cam.mode = {"f32": d.MODE_F32, "f64": d.MODE_F64, "f32plain": d.MODE_F32_PLAIN}[args.mode]
+    cam.seed = args.seed
+    scene = ddev.DeviceScene(spheres, local_rank)
+    renderer = partition.DistributedRenderer(
+        cam, partition.gpu_render_rows(scene, samples_per_item=args.samples_per_item),
+        partition.gpu_alloc(local_rank), rank=rank, world_size=world)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        renderer.step()
+    sync()
+    t0 = time.perf_counter()
+    segs = samples = 0
+    kernel_ms = resolve_ms = 0.0
+    for _ in range(args.steps):
+        image, st = renderer.step()
+        segs += st.segments
+        samples += st.samples
+        kernel_ms += st.kernel_ms
+        resolve_ms += st.resolve_ms
+    sync()
+    elapsed = time.perf_counter() - t0
+
+    tot = torch.tensor([float(segs), float(samples), elapsed], dtype=torch.float64, device="cuda")
+    if world > 1:
+        sums = tot.clone()
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+        mx = tot.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        total_segs, total_samples, elapsed = sums[0].item(), sums[1].item(), mx[2].item()
+    else:
+        total_segs, total_samples = float(segs), float(samples)
+
+    if rank == 0:
+        n_spheres = len(spheres)
+        k_s = kernel_ms / 1e3 / max(args.steps, 1)           # this rank's average trace-kernel duration
+        flops_per_launch = FLOP_PER_TEST * n_spheres * (segs / max(args.steps, 1))
+        achieved = flops_per_launch / k_s if k_s > 0 else 0.0
+        out = {
+            "metric": "Mrays/sec (whole node) on RTIOW final scene 1200x675 500spp",
+            "value": total_segs / elapsed / 1e6,
+            "unit": "Mrays/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / max(args.steps, 1) * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": {"f32": "f32", "f64": "f64", "f32plain": "f32"}[args.mode],
+            "data": "synthetic",
+            "config": {"workload": "RTIOW final scene (%d spheres, Philox seed %d) %dx%d, %d spp, depth %d; "
+                                   "interleaved scanlines over %d GPU(s), whole scene replicated, one all-gather "
+                                   "of the packed image per step" % (n_spheres, args.seed, args.width,
+                                                                    cam.image_height, args.spp, args.depth, world),
+                       "spheres": n_spheres, "width": args.width, "height": cam.image_height, "spp": args.spp,
+                       "max_depth": args.depth, "mode": args.mode, "partition": "rows j %% %d" % world},
+            "samples_per_s": total_samples / elapsed,
+            "segments_per_sample": total_segs / max(total_samples, 1.0),
+            "roofline": {
+                "bound": "valu",
+                "achieved": achieved / 1e12,
+                "peak": PEAK_FP32_VALU / 1e12,
+                "unit": "TFLOP/s",
+                "frac": achieved / PEAK_FP32_VALU,
+                "traffic": None,
+                "kernel": "render_f32_kernel" if args.mode == "f32" else "render_ref_kernel",
+                "kernel_ms": k_s * 1e3,
+                "resolve_ms": resolve_ms / max(args.steps, 1),
+                "note": "algorithmic FLOP = 18 x spheres x segments of one launch (rank 0), over the launch's "
+                        "HIP-event duration; FP32 vector peak 157.3 TFLOP/s",
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            one, many = cpu_baseline(spheres, args.width, args.depth, args.seed)
+            out["cpu_baseline"] = one
+            out["cpu_baseline_all_cores"] = many
+        print(json.dumps(out))
+    scene.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,18 @@
+"""MI355X (gfx950) backend for the path tracer's per-pixel render path.
+
+The directory name has a hyphen, so import it with
+``importlib.import_module("distributed-raytracer_amd")`` or through the
+``dray_amd`` shim module at the repository root.
+"""
+from . import _ffi, partition, raytracer  # noqa: F401
+from ._ffi import (FLAG_COMPACT_ROWS, FLAG_ITERATIVE_PRODUCT, MODE_F32, MODE_F32_PLAIN, MODE_F64, DrayError)  # noqa: F401
+from .raytracer import (Camera, DefaultMaterial, Dialectric, Hittable, HittableList, Lambertian, Material, Metal,  # noqa: F401
+                        Sphere, camera_final, camera_three_spheres, flatten_world, scene_final, scene_three_spheres)
+
+
+def version():
+    return _ffi.lib().dray_version().decode()
+
+
+def device_count():
+    return _ffi.lib().dray_device_count()

@@ -1,0 +1,536 @@
+// C ABI of libdray_hip.so (declared in include/dray.h): argument checking, the
+// host-side camera set-up, scene upload and launch sequencing.  Host code only;
+// the kernels live in render_ref.hip and render_f32.hip.  Build with
+// -ffp-contract=off: the camera maths below must round like the reference's
+// plain f64 expressions (src/raytracer/camera.rs:169-206).
+#pragma clang fp contract(off)
+
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "dray_internal.h"
+
+using namespace dray;
+
+struct dray_scene {
+    int32_t device = 0;
+    SceneDev dev;
+    DeviceCounters* d_counters = nullptr;
+    unsigned long long* d_accum = nullptr; // fixed-point colour sums of the f32 kernel
+    size_t accum_capacity = 0;             // in u64 words
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+};
+
+namespace {
+
+thread_local char g_detail[256] = "";
+
+int hip_fail(hipError_t e, const char* what) {
+    snprintf(g_detail, sizeof g_detail, "%s: %s", what, hipGetErrorString(e));
+    return DRAY_ERR_HIP;
+}
+
+#define HIP_TRY(expr)                                      \
+    do {                                                   \
+        hipError_t e__ = (expr);                           \
+        if (e__ != hipSuccess) return hip_fail(e__, #expr); \
+    } while (0)
+
+// RAII: make `device` current for the scope, restore the caller's device afterwards.
+struct DeviceGuard {
+    int prev = -1;
+    bool changed = false;
+    hipError_t err = hipSuccess;
+    explicit DeviceGuard(int device) {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != device) {
+            err = hipSetDevice(device);
+            changed = err == hipSuccess;
+        }
+    }
+    ~DeviceGuard() {
+        if (changed) (void)hipSetDevice(prev);
+    }
+};
+
+struct D3 {
+    double x, y, z;
+};
+D3 sub(D3 a, D3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+D3 add(D3 a, D3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+D3 scale(D3 a, double s) { return {a.x * s, a.y * s, a.z * s}; }
+D3 divs(D3 a, double s) { return {a.x / s, a.y / s, a.z / s}; }
+D3 neg(D3 a) { return {-a.x, -a.y, -a.z}; }
+double dot(D3 a, D3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+D3 cross(D3 a, D3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+D3 unit(D3 a) { return divs(a, std::sqrt(dot(a, a))); }
+D3 ld(const double* p) { return {p[0], p[1], p[2]}; }
+void stv(double* p, D3 a) { p[0] = a.x; p[1] = a.y; p[2] = a.z; }
+
+double degrees_to_radians(double d) { return d * 3.14159265358979323846264338327950288 / 180.0; } // prelude.rs:17-20
+
+bool camera_ok(const dray_camera* cam) {
+    return cam && cam->image_width >= 1 && std::isfinite(cam->aspect_ratio) && cam->aspect_ratio > 0.;
+}
+
+// Philox4x32-10 on the host, for the scene recipe only.
+void philox_host(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3], k0 = key[0], k1 = key[1];
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c0 = n0; c1 = (uint32_t)p1; c2 = n2; c3 = (uint32_t)p0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+struct SceneStream {
+    uint32_t key[2];
+    uint32_t n = 0;
+    double next() {
+        const uint32_t ctr[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, n >> 2};
+        uint32_t w[4];
+        philox_host(ctr, key, w);
+        const double u = (double)(w[n & 3u] >> 8) * (1.0 / 16777216.0);
+        ++n;
+        return u;
+    }
+    double range(double lo, double hi) { return lo + (hi - lo) * next(); } // prelude.rs:27-30
+};
+
+void put_sphere(dray_sphere* o, double x, double y, double z, double r, uint32_t kind, double a0, double a1, double a2,
+                double f) {
+    std::memset(o, 0, sizeof *o);
+    o->center[0] = x; o->center[1] = y; o->center[2] = z;
+    o->radius = r;
+    o->kind = kind;
+    o->albedo[0] = a0; o->albedo[1] = a1; o->albedo[2] = a2;
+    o->fuzz_or_ior = f;
+}
+
+template <typename T>
+CamDev<T> make_cam(const dray_camera& cam, const dray_camera_derived& d) {
+    CamDev<T> c{};
+    for (int q = 0; q < 3; ++q) {
+        c.center[q] = (T)d.center[q];
+        c.p00[q] = (T)d.pixel00_loc[q];
+        c.du[q] = (T)d.pixel_delta_u[q];
+        c.dv[q] = (T)d.pixel_delta_v[q];
+        c.ddu[q] = (T)d.defocus_disk_u[q];
+        c.ddv[q] = (T)d.defocus_disk_v[q];
+    }
+    c.W = cam.image_width;
+    c.H = d.image_height;
+    c.spp = cam.samples_per_pixel;
+    c.max_depth = cam.max_depth;
+    c.defocus = cam.defocus_angle <= 0. ? 0 : 1; // camera.rs:247
+    return c;
+}
+
+constexpr double kWideRadius = 32.0; // spheres at least this large are intersected in f64 by the f32 kernel
+
+void scene_free(dray_scene* s) {
+    if (!s) return;
+    DeviceGuard g(s->device);
+    SceneDev& d = s->dev;
+    (void)hipFree(d.geom64); (void)hipFree(d.mat64); (void)hipFree(d.kind);
+    (void)hipFree(d.geom32); (void)hipFree(d.mat32);
+    (void)hipFree(d.narrow_geom); (void)hipFree(d.narrow_index); (void)hipFree(d.wide_index);
+    (void)hipFree(s->d_counters); (void)hipFree(s->d_accum);
+    for (auto& e : s->ev)
+        if (e) (void)hipEventDestroy(e);
+    delete s;
+}
+
+template <typename T>
+int upload(T** dst, const std::vector<T>& src) {
+    *dst = nullptr;
+    const size_t bytes = (src.empty() ? 1 : src.size()) * sizeof(T);
+    HIP_TRY(hipMalloc((void**)dst, bytes));
+    if (!src.empty()) HIP_TRY(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+    return DRAY_OK;
+}
+
+int scene_create_impl(const dray_sphere* sp, size_t n, int32_t device, dray_scene** out) {
+    if (!out) return DRAY_ERR_INVALID_ARG;
+    *out = nullptr;
+    if ((!sp && n) || n > 0x7fffffffu) return DRAY_ERR_INVALID_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return DRAY_ERR_NO_DEVICE;
+    if (device < 0) HIP_TRY(hipGetDevice(&device));
+    if (device >= ndev) return DRAY_ERR_INVALID_ARG;
+    for (size_t k = 0; k < n; ++k)
+        if (sp[k].kind > DRAY_MAT_DIELECTRIC) return DRAY_ERR_UNSUPPORTED;
+
+    DeviceGuard g(device);
+    if (g.err != hipSuccess) return hip_fail(g.err, "hipSetDevice");
+    dray_scene* s = new (std::nothrow) dray_scene();
+    if (!s) return DRAY_ERR_INTERNAL;
+    s->device = device;
+    SceneDev& d = s->dev;
+    d.n = (int32_t)n;
+
+    std::vector<double> g64(4 * n), m64(4 * n);
+    std::vector<float> g32(4 * n), m32(4 * n), ng;
+    std::vector<uint32_t> kind(n);
+    std::vector<int32_t> nidx, widx;
+    for (size_t k = 0; k < n; ++k) {
+        const double r = std::fmax(sp[k].radius, 0.); // sphere.rs:14
+        double f = sp[k].fuzz_or_ior;
+        if (sp[k].kind == DRAY_MAT_METAL) f = f < 1.0 ? f : 1.0; // material.rs:67
+        for (int q = 0; q < 3; ++q) {
+            g64[4 * k + q] = sp[k].center[q];
+            m64[4 * k + q] = sp[k].albedo[q];
+            g32[4 * k + q] = (float)sp[k].center[q];
+            m32[4 * k + q] = (float)sp[k].albedo[q];
+        }
+        g64[4 * k + 3] = r; m64[4 * k + 3] = f;
+        g32[4 * k + 3] = (float)r; m32[4 * k + 3] = (float)f;
+        kind[k] = sp[k].kind;
+        if (r >= kWideRadius) {
+            widx.push_back((int32_t)k);
+        } else {
+            nidx.push_back((int32_t)k);
+            ng.push_back((float)sp[k].center[0]); ng.push_back((float)sp[k].center[1]); ng.push_back((float)sp[k].center[2]);
+            ng.push_back((float)(r * r));
+        }
+    }
+    d.n_narrow = (int32_t)nidx.size();
+    d.n_wide = (int32_t)widx.size();
+    while (nidx.size() % 8 != 0) { // padding entries can never be hit: their discriminant is -1e30 + h*h - |oc|^2 < 0
+        nidx.push_back(-1);
+        ng.push_back(0.f); ng.push_back(0.f); ng.push_back(0.f); ng.push_back(-1e30f);
+    }
+    d.n_narrow_padded = (int32_t)nidx.size();
+
+    int rc = DRAY_OK;
+    if ((rc = upload(&d.geom64, g64)) || (rc = upload(&d.mat64, m64)) || (rc = upload(&d.kind, kind)) ||
+        (rc = upload(&d.geom32, g32)) || (rc = upload(&d.mat32, m32)) || (rc = upload(&d.narrow_geom, ng)) ||
+        (rc = upload(&d.narrow_index, nidx)) || (rc = upload(&d.wide_index, widx))) {
+        scene_free(s);
+        return rc;
+    }
+    hipError_t e = hipMalloc((void**)&s->d_counters, sizeof(DeviceCounters));
+    for (auto& ev : s->ev)
+        if (e == hipSuccess) e = hipEventCreate(&ev);
+    if (e != hipSuccess) {
+        scene_free(s);
+        return hip_fail(e, "scene workspace");
+    }
+    *out = s;
+    return DRAY_OK;
+}
+
+int render_device_impl(const dray_camera* cam, dray_scene* scene, uint32_t* d_color, double* d_raw, int32_t* d_count,
+                       size_t buf_len, const dray_opts* opts_in, void* stream_v, dray_stats* stats) {
+    const auto t_begin = std::chrono::steady_clock::now();
+    if (!camera_ok(cam) || !scene || !d_color) return DRAY_ERR_INVALID_ARG;
+    dray_opts opts;
+    if (opts_in) opts = *opts_in; else dray_opts_default(&opts);
+    if (opts.mode > DRAY_MODE_F32_PLAIN) return DRAY_ERR_INVALID_ARG;
+    if (opts.row_step == 0) opts.row_step = 1;
+    if (opts.row_step < 0 || opts.row_begin < 0) return DRAY_ERR_INVALID_ARG;
+    if (opts.device >= 0 && opts.device != scene->device) return DRAY_ERR_INVALID_ARG;
+
+    dray_camera_derived dv;
+    int rc = dray_camera_initialize(cam, &dv);
+    if (rc) return rc;
+    const int32_t W = cam->image_width, H = dv.image_height;
+    Partition part{};
+    part.row_begin = opts.row_begin;
+    part.row_step = opts.row_step;
+    part.n_rows = opts.row_begin < H ? (H - opts.row_begin + opts.row_step - 1) / opts.row_step : 0;
+    part.compact = (opts.flags & DRAY_FLAG_COMPACT_ROWS) ? 1 : 0;
+    const size_t need = part.compact ? (size_t)part.n_rows * (size_t)W : (size_t)W * (size_t)H;
+    if (buf_len < need) return DRAY_ERR_BUFFER_TOO_SMALL;
+    const bool exact_product = opts.mode != DRAY_MODE_F32 && !(opts.flags & DRAY_FLAG_ITERATIVE_PRODUCT);
+    if (exact_product && cam->max_depth > kExactMaxDepth) return DRAY_ERR_UNSUPPORTED;
+
+    if (stats) {
+        std::memset(stats, 0, sizeof *stats);
+        stats->image_height = H;
+        stats->rows_rendered = part.n_rows;
+        stats->n_spheres = scene->dev.n;
+        stats->n_wide_spheres = opts.mode == DRAY_MODE_F32 ? scene->dev.n_wide : 0;
+    }
+    // camera.rs:217: no samples, no writes
+    if (cam->samples_per_pixel <= 0 || part.n_rows == 0) return DRAY_OK;
+
+    DeviceGuard g(scene->device);
+    if (g.err != hipSuccess) return hip_fail(g.err, "hipSetDevice");
+    hipStream_t stream = (hipStream_t)stream_v;
+    const RngKey key = {(uint32_t)opts.seed, (uint32_t)(opts.seed >> 32), opts.sample_offset};
+
+    HIP_TRY(hipMemsetAsync(scene->d_counters, 0, sizeof(DeviceCounters), stream));
+    if (opts.mode == DRAY_MODE_F32) {
+        const CamDev<float> c = make_cam<float>(*cam, dv);
+        const F32Plan plan = plan_render_f32(c, part, opts.samples_per_item, scene->device);
+        if (plan.accum_words > scene->accum_capacity) {
+            if (scene->d_accum) HIP_TRY(hipFree(scene->d_accum));
+            scene->d_accum = nullptr;
+            scene->accum_capacity = 0;
+            HIP_TRY(hipMalloc((void**)&scene->d_accum, plan.accum_words * sizeof(unsigned long long)));
+            scene->accum_capacity = plan.accum_words;
+        }
+        HIP_TRY(hipMemsetAsync(scene->d_accum, 0, plan.accum_words * sizeof(unsigned long long), stream));
+        HIP_TRY(hipEventRecord(scene->ev[0], stream));
+        if (cam->max_depth > 0) // camera.rs:265: with no depth every sample is black and no ray is traced
+            HIP_TRY(launch_render_f32(c, scene->dev, part, key, plan, scene->d_accum, scene->d_counters, stream));
+        HIP_TRY(hipEventRecord(scene->ev[1], stream));
+        HIP_TRY(launch_resolve_f32(c, part, scene->d_accum, d_color, d_raw, d_count, stream));
+        HIP_TRY(hipEventRecord(scene->ev[2], stream));
+    } else {
+        HIP_TRY(hipEventRecord(scene->ev[0], stream));
+        if (opts.mode == DRAY_MODE_F64)
+            HIP_TRY(launch_render_ref_f64(make_cam<double>(*cam, dv), scene->dev, part, key, opts.flags, d_color, d_raw,
+                                          d_count, scene->d_counters, stream));
+        else
+            HIP_TRY(launch_render_ref_f32(make_cam<float>(*cam, dv), scene->dev, part, key, opts.flags, d_color, d_raw,
+                                          d_count, scene->d_counters, stream));
+        HIP_TRY(hipEventRecord(scene->ev[1], stream));
+        HIP_TRY(hipEventRecord(scene->ev[2], stream));
+    }
+
+    if (stats) {
+        HIP_TRY(hipEventSynchronize(scene->ev[2]));
+        DeviceCounters hc{};
+        HIP_TRY(hipMemcpy(&hc, scene->d_counters, sizeof hc, hipMemcpyDeviceToHost));
+        float k_ms = 0.f, r_ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&k_ms, scene->ev[0], scene->ev[1]));
+        HIP_TRY(hipEventElapsedTime(&r_ms, scene->ev[1], scene->ev[2]));
+        stats->segments = hc.segments;
+        stats->samples = (opts.mode == DRAY_MODE_F32 && cam->max_depth <= 0)
+                             ? (uint64_t)part.n_rows * (uint64_t)W * (uint64_t)cam->samples_per_pixel
+                             : hc.samples;
+        stats->kernel_ms = k_ms;
+        stats->resolve_ms = r_ms;
+        stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    }
+    return DRAY_OK;
+}
+
+int render_host_impl(const dray_camera* cam, const dray_sphere* spheres, size_t n, uint32_t* color, double* raw,
+                     int32_t* count, size_t buf_len, const dray_opts* opts_in, dray_stats* stats) {
+    const auto t_begin = std::chrono::steady_clock::now();
+    if (!camera_ok(cam) || !color || (!spheres && n)) return DRAY_ERR_INVALID_ARG;
+    dray_opts opts;
+    if (opts_in) opts = *opts_in; else dray_opts_default(&opts);
+    if (opts.row_step == 0) opts.row_step = 1;
+    if (opts.row_step < 0 || opts.row_begin < 0) return DRAY_ERR_INVALID_ARG;
+    dray_camera_derived dv;
+    int rc = dray_camera_initialize(cam, &dv);
+    if (rc) return rc;
+    const size_t W = (size_t)cam->image_width, H = (size_t)dv.image_height;
+    const bool compact = (opts.flags & DRAY_FLAG_COMPACT_ROWS) != 0;
+    const size_t n_rows = (size_t)opts.row_begin < H ? (H - opts.row_begin + opts.row_step - 1) / opts.row_step : 0;
+    const size_t used = compact ? n_rows * W : W * H; // entries past this are never touched (main.rs:69-73)
+    if (buf_len < used) return DRAY_ERR_BUFFER_TOO_SMALL;
+
+    dray_scene* scene = nullptr;
+    rc = scene_create_impl(spheres, n, opts.device, &scene);
+    if (rc) return rc;
+    opts.device = scene->device;
+    DeviceGuard g(scene->device);
+    uint32_t* d_color = nullptr;
+    double* d_raw = nullptr;
+    int32_t* d_count = nullptr;
+    auto cleanup = [&]() {
+        (void)hipFree(d_color); (void)hipFree(d_raw); (void)hipFree(d_count);
+        scene_free(scene);
+    };
+    auto fail = [&](hipError_t e, const char* what) { int r = hip_fail(e, what); cleanup(); return r; };
+    const size_t alloc = used ? used : 1;
+    hipError_t e;
+    if ((e = hipMalloc((void**)&d_color, alloc * sizeof(uint32_t))) != hipSuccess) return fail(e, "hipMalloc color");
+    if ((e = hipMemcpy(d_color, color, used * sizeof(uint32_t), hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "upload color");
+    if (raw) {
+        if ((e = hipMalloc((void**)&d_raw, alloc * 3 * sizeof(double))) != hipSuccess) return fail(e, "hipMalloc raw");
+        if ((e = hipMemcpy(d_raw, raw, used * 3 * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "upload raw");
+    }
+    if (count) {
+        if ((e = hipMalloc((void**)&d_count, alloc * sizeof(int32_t))) != hipSuccess) return fail(e, "hipMalloc count");
+        if ((e = hipMemcpy(d_count, count, used * sizeof(int32_t), hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "upload count");
+    }
+    dray_stats local{};
+    rc = render_device_impl(cam, scene, d_color, d_raw, d_count, used, &opts, nullptr, &local);
+    if (rc == DRAY_OK) {
+        if ((e = hipDeviceSynchronize()) != hipSuccess) return fail(e, "hipDeviceSynchronize");
+        if ((e = hipMemcpy(color, d_color, used * sizeof(uint32_t), hipMemcpyDeviceToHost)) != hipSuccess) return fail(e, "download color");
+        if (raw && (e = hipMemcpy(raw, d_raw, used * 3 * sizeof(double), hipMemcpyDeviceToHost)) != hipSuccess) return fail(e, "download raw");
+        if (count && (e = hipMemcpy(count, d_count, used * sizeof(int32_t), hipMemcpyDeviceToHost)) != hipSuccess) return fail(e, "download count");
+    }
+    cleanup();
+    if (stats) {
+        *stats = local;
+        stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    }
+    return rc;
+}
+
+} // namespace
+
+// ------------------------------------------------------------------ C ABI ----
+
+extern "C" {
+
+const char* dray_version(void) { return "dray-hip 0.1.0 (gfx950)"; }
+
+const char* dray_strerror(int status) {
+    switch (status) {
+    case DRAY_OK: return "ok";
+    case DRAY_ERR_INVALID_ARG: return "invalid argument";
+    case DRAY_ERR_BUFFER_TOO_SMALL: return "buffer too small for image_width x image_height";
+    case DRAY_ERR_UNSUPPORTED: return "unsupported scene object, material or depth";
+    case DRAY_ERR_NO_DEVICE: return "no HIP device";
+    case DRAY_ERR_HIP: return g_detail[0] ? g_detail : "HIP runtime error";
+    case DRAY_ERR_INTERNAL: return "internal error";
+    default: return "unknown status";
+    }
+}
+
+int dray_device_count(void) {
+    int n = 0;
+    const hipError_t e = hipGetDeviceCount(&n);
+    if (e == hipErrorNoDevice) return 0;
+    if (e != hipSuccess) return hip_fail(e, "hipGetDeviceCount");
+    return n;
+}
+
+void dray_opts_default(dray_opts* o) {
+    if (!o) return;
+    std::memset(o, 0, sizeof *o);
+    o->seed = 1;
+    o->mode = DRAY_MODE_F32;
+    o->device = -1;
+    o->row_step = 1;
+}
+
+void dray_camera_default(dray_camera* cam) { // camera.rs:147-163
+    if (!cam) return;
+    std::memset(cam, 0, sizeof *cam);
+    cam->aspect_ratio = 1.0;
+    cam->image_width = 100;
+    cam->samples_per_pixel = 10;
+    cam->max_depth = 10;
+    cam->vfov = 90.;
+    cam->lookat[2] = -1.;
+    cam->vup[1] = 1.;
+    cam->defocus_angle = 0.;
+    cam->focus_dist = 10.;
+}
+
+int dray_camera_initialize(const dray_camera* cam, dray_camera_derived* out) { // camera.rs:169-206
+    if (!camera_ok(cam) || !out) return DRAY_ERR_INVALID_ARG;
+    std::memset(out, 0, sizeof *out);
+    const double hh = (double)cam->image_width / cam->aspect_ratio;
+    int32_t H = hh >= 2147483647.0 ? 2147483647 : (int32_t)hh; // `as i32` saturates
+    if (H < 1) H = 1;
+    out->image_height = H;
+    out->pixel_samples_scale = 1.0 / (double)cam->samples_per_pixel;
+    const D3 center = ld(cam->lookfrom);
+    const double theta = degrees_to_radians(cam->vfov);
+    const double h = std::tan(theta / 2.);
+    const double viewport_height = 2. * h * cam->focus_dist;
+    const double viewport_width = viewport_height * ((double)cam->image_width / (double)H);
+    const D3 w = unit(sub(ld(cam->lookfrom), ld(cam->lookat)));
+    const D3 u = unit(cross(ld(cam->vup), w));
+    const D3 v = cross(w, u);
+    const D3 viewport_u = scale(u, viewport_width);
+    const D3 viewport_v = scale(neg(v), viewport_height);
+    const D3 du = divs(viewport_u, (double)cam->image_width);
+    const D3 dvv = divs(viewport_v, (double)H);
+    const D3 upper_left = sub(sub(sub(center, scale(w, cam->focus_dist)), divs(viewport_u, 2.)), divs(viewport_v, 2.));
+    const D3 p00 = add(upper_left, scale(add(du, dvv), 0.5));
+    const double defocus_radius = cam->focus_dist * std::tan(degrees_to_radians(cam->defocus_angle / 2.));
+    stv(out->center, center);
+    stv(out->pixel00_loc, p00);
+    stv(out->pixel_delta_u, du);
+    stv(out->pixel_delta_v, dvv);
+    stv(out->u, u); stv(out->v, v); stv(out->w, w);
+    stv(out->defocus_disk_u, scale(u, defocus_radius));
+    stv(out->defocus_disk_v, scale(v, defocus_radius));
+    return DRAY_OK;
+}
+
+int dray_render(const dray_camera* cam, const dray_sphere* spheres, size_t n_spheres, uint32_t* color, double* raw,
+                int32_t* count, size_t buf_len, const dray_opts* opts, dray_stats* stats) {
+    try {
+        return render_host_impl(cam, spheres, n_spheres, color, raw, count, buf_len, opts, stats);
+    } catch (...) {
+        return DRAY_ERR_INTERNAL;
+    }
+}
+
+int dray_scene_create(const dray_sphere* spheres, size_t n_spheres, int32_t device, dray_scene** out) {
+    try {
+        return scene_create_impl(spheres, n_spheres, device, out);
+    } catch (...) {
+        return DRAY_ERR_INTERNAL;
+    }
+}
+
+void dray_scene_destroy(dray_scene* scene) {
+    try {
+        scene_free(scene);
+    } catch (...) {
+    }
+}
+
+int dray_render_device(const dray_camera* cam, dray_scene* scene, uint32_t* d_color, double* d_raw, int32_t* d_count,
+                       size_t buf_len, const dray_opts* opts, void* stream, dray_stats* stats) {
+    try {
+        return render_device_impl(cam, scene, d_color, d_raw, d_count, buf_len, opts, stream, stats);
+    } catch (...) {
+        return DRAY_ERR_INTERNAL;
+    }
+}
+
+int dray_scene_three_spheres(dray_sphere* out, size_t cap) {
+    if (!out || cap < 4) return DRAY_ERR_BUFFER_TOO_SMALL;
+    put_sphere(&out[0], 0., -100.5, -1., 100., DRAY_MAT_LAMBERTIAN, 0.8, 0.8, 0.0, 0.);
+    put_sphere(&out[1], 0., 0., -1.2, 0.5, DRAY_MAT_LAMBERTIAN, 0.1, 0.2, 0.5, 0.);
+    put_sphere(&out[2], -1., 0., -1., 0.5, DRAY_MAT_DIELECTRIC, 0., 0., 0., 1.5);
+    put_sphere(&out[3], 1., 0., -1., 0.5, DRAY_MAT_METAL, 0.8, 0.6, 0.2, 1.0);
+    return 4;
+}
+
+int dray_scene_final(uint64_t seed, dray_sphere* out, size_t cap) { // main.rs:13-50
+    if (!out || cap < 1) return DRAY_ERR_BUFFER_TOO_SMALL;
+    SceneStream rs;
+    rs.key[0] = (uint32_t)seed;
+    rs.key[1] = (uint32_t)(seed >> 32);
+    size_t n = 0;
+    put_sphere(&out[n++], 0., -1000., 0., 1000., DRAY_MAT_LAMBERTIAN, 0.5, 0.5, 0.5, 0.);
+    for (int a = -11; a < 11; ++a)
+        for (int b = -11; b < 11; ++b) {
+            const double choose_mat = rs.next();
+            const double cx = (double)a + 0.9 * rs.next();
+            const double cz = (double)b + 0.9 * rs.next();
+            const D3 dlt = sub(D3{cx, 0.2, cz}, D3{4., 0.2, 0.});
+            if (std::sqrt(dot(dlt, dlt)) > 0.9) {
+                if (n >= cap) return DRAY_ERR_BUFFER_TOO_SMALL;
+                if (choose_mat < 0.8) {
+                    const double r0 = rs.next(), r1 = rs.next(), r2 = rs.next();
+                    const double s0 = rs.next(), s1 = rs.next(), s2 = rs.next();
+                    put_sphere(&out[n++], cx, 0.2, cz, 0.2, DRAY_MAT_LAMBERTIAN, r0 * s0, r1 * s1, r2 * s2, 0.);
+                } else if (choose_mat < 0.95) {
+                    const double a0 = rs.range(0.5, 1.), a1 = rs.range(0.5, 1.), a2 = rs.range(0.5, 1.);
+                    const double fuzz = rs.range(0., 0.5);
+                    put_sphere(&out[n++], cx, 0.2, cz, 0.2, DRAY_MAT_METAL, a0, a1, a2, fuzz);
+                } else {
+                    put_sphere(&out[n++], cx, 0.2, cz, 0.2, DRAY_MAT_DIELECTRIC, 0., 0., 0., 1.5);
+                }
+            }
+        }
+    if (n + 3 > cap) return DRAY_ERR_BUFFER_TOO_SMALL;
+    put_sphere(&out[n++], 0., 1., 0., 1.0, DRAY_MAT_DIELECTRIC, 0., 0., 0., 1.5);
+    put_sphere(&out[n++], -4., 1., 0., 1.0, DRAY_MAT_LAMBERTIAN, 0.4, 0.2, 0.1, 0.);
+    put_sphere(&out[n++], 4., 1., 0., 1.0, DRAY_MAT_METAL, 0.7, 0.6, 0.5, 0.0);
+    return (int)n;
+}
+
+} // extern "C"

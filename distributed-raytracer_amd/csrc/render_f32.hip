@@ -1,0 +1,395 @@
+// f32 throughput render kernel for gfx950.
+//
+// One persistent launch.  Every lane carries one path; the recursion of the
+// reference's ray_color (src/raytracer/camera.rs:264-282) is the iterative
+// bounce loop of its twin ray_color_iteration (camera.rs:118-144) with an
+// explicit throughput.  When a lane's path ends it starts the next sample of
+// its work item, and when the item is used up the wave draws new items from a
+// global queue, so all 64 lanes stay inside the sphere scan, which is the same
+// instruction stream for every lane whatever its pixel, sample or bounce.
+//
+// A work item is `samples_per_item` consecutive samples of one pixel.  Sample
+// colours are summed as 36.28 fixed-point integers (integer addition is
+// associative), so the image does not depend on the item size, the partition,
+// the GPU count or the order in which lanes finish.
+//
+// The sphere list is scanned in insertion order (hittable_list.rs:65-70).
+// "Narrow" spheres are tested in f32 with the geometry arriving through scalar
+// loads (the address is the same for all lanes); "wide" spheres, whose radius is
+// so large that |oc|^2 - r^2 cancels catastrophically in f32 (the 1000-radius
+// ground of src/main.rs:14), are tested in f64.
+#include "dray_device.h"
+#include "dray_internal.h"
+
+namespace dray {
+namespace {
+
+constexpr float kFixScale = 268435456.f;      // 2^28
+constexpr double kFixInv = 1.0 / 268435456.0; // 2^-28
+constexpr float kFixMax = 15.99f;             // a sample colour channel is clamped to [0, 15.99]
+constexpr int kUnroll = 8;
+
+struct F3 {
+    float x, y, z;
+};
+__device__ __forceinline__ F3 operator+(F3 a, F3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ F3 operator-(F3 a, F3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ F3 operator*(F3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ float dot(F3 a, F3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
+__device__ __forceinline__ float rsq(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+
+// vec3.rs:76-84: rejection sampling in the cube; attempt a = words 0..2 of block a of the stage.
+__device__ __forceinline__ F3 random_unit_vector(const Stream& st) {
+    for (uint32_t a = 0;; ++a) {
+        uint32_t w[4];
+        st.block(a, w);
+        F3 p = {fmaf(2.f, u01<float>(w[0]), -1.f), fmaf(2.f, u01<float>(w[1]), -1.f), fmaf(2.f, u01<float>(w[2]), -1.f)};
+        const float l2 = dot(p, p);
+        if (1e-30f <= l2 && l2 <= 1.f) return p * rsq(l2);
+    }
+}
+
+struct PathRay {
+    F3 o, d;    // origin, unit direction
+    float tmin; // 0.001 in units of the un-normalised direction (camera.rs:270)
+};
+
+__device__ __forceinline__ void set_dir(PathRay& r, F3 dir) {
+    const float l2 = dot(dir, dir);
+    const float inv = rsq(l2);
+    r.d = dir * inv;
+    r.tmin = 0.001f * (l2 * inv);
+}
+
+// camera.rs:238-262
+__device__ __forceinline__ void camera_ray(const CamDev<float>& cam, int32_t i, int32_t j, const Stream& st, PathRay& r) {
+    uint32_t w[4];
+    st.block(0, w);
+    const float fx = (float)i + (u01<float>(w[0]) - 0.5f), fy = (float)j + (u01<float>(w[1]) - 0.5f);
+    F3 ps = {fmaf(fy, cam.dv[0], fmaf(fx, cam.du[0], cam.p00[0])), fmaf(fy, cam.dv[1], fmaf(fx, cam.du[1], cam.p00[1])),
+             fmaf(fy, cam.dv[2], fmaf(fx, cam.du[2], cam.p00[2]))};
+    F3 o = {cam.center[0], cam.center[1], cam.center[2]};
+    if (cam.defocus) {
+        float px, py;
+        for (uint32_t m = 0;; ++m) { // vec3.rs:111-118; attempt m = uniforms 2+2m, 3+2m
+            const uint32_t d0 = 2u + 2u * m;
+            if (m > 0 && (d0 & 3u) == 0u) st.block(d0 >> 2, w);
+            const bool hi = (d0 & 3u) != 0u;
+            px = fmaf(2.f, u01<float>(hi ? w[2] : w[0]), -1.f);
+            py = fmaf(2.f, u01<float>(hi ? w[3] : w[1]), -1.f);
+            if (fmaf(px, px, py * py) < 1.f) break;
+        }
+        o.x = fmaf(py, cam.ddv[0], fmaf(px, cam.ddu[0], o.x));
+        o.y = fmaf(py, cam.ddv[1], fmaf(px, cam.ddu[1], o.y));
+        o.z = fmaf(py, cam.ddv[2], fmaf(px, cam.ddu[2], o.z));
+    }
+    r.o = o;
+    set_dir(r, ps - o);
+}
+
+__device__ __forceinline__ uint32_t to_fixed(float c) {
+    // NaN and negatives become 0, large values saturate.
+    return (uint32_t)(fminf(fmaxf(c, 0.f), kFixMax) * kFixScale);
+}
+
+__global__ __launch_bounds__(256) void render_f32_kernel(
+    CamDev<float> cam, const float4* __restrict__ narrow_geom, const int32_t* __restrict__ narrow_index,
+    int32_t n_narrow_padded, const int32_t* __restrict__ wide_index, int32_t n_wide,
+    const double* __restrict__ geom64, const float4* __restrict__ geom32, const float4* __restrict__ mat32,
+    const uint32_t* __restrict__ kind, Partition part, RngKey key, int32_t samples_per_item, int32_t n_chunks,
+    unsigned long long n_items, unsigned long long* __restrict__ accum, DeviceCounters* counters) {
+    const int lane = __lane_id();
+    const long long npix = (long long)part.n_rows * cam.W;
+
+    bool alive = false, done = false, have_item = false;
+    int32_t s_next = 0, s_end = 0;
+    long long pix = 0;
+    int32_t pi = 0, pj = 0;
+    unsigned long long acc_r = 0, acc_g = 0, acc_b = 0;
+    uint32_t n_seg = 0, n_samples = 0;
+
+    PathRay ray = {{0.f, 0.f, 0.f}, {0.f, 0.f, 1.f}, 0.001f};
+    F3 thr = {1.f, 1.f, 1.f};
+    int32_t stage = 1;
+    Stream st = {key.k0, key.k1, 0u, 0u, 0u};
+
+    for (;;) {
+        // ---- refill ---------------------------------------------------------------------------
+        bool need_item = !alive && !done && s_next >= s_end;
+        if (need_item && have_item) {
+            atomicAdd(&accum[0 * npix + pix], acc_r);
+            atomicAdd(&accum[1 * npix + pix], acc_g);
+            atomicAdd(&accum[2 * npix + pix], acc_b);
+            have_item = false;
+        }
+        const unsigned long long want = __ballot(need_item);
+        if (want != 0ull) {
+            const int leader = __ffsll((long long)want) - 1;
+            unsigned long long base = 0ull;
+            if (lane == leader) base = atomicAdd(&counters->next_item, (unsigned long long)__popcll(want));
+            base = __shfl(base, leader, 64);
+            if (need_item) {
+                const unsigned long long item = base + (unsigned long long)__popcll(want & ((1ull << lane) - 1ull));
+                if (item >= n_items) {
+                    done = true;
+                } else {
+                    pix = (long long)(item / (unsigned long long)n_chunks);
+                    const int32_t chunk = (int32_t)(item - (unsigned long long)pix * (unsigned long long)n_chunks);
+                    const int32_t r = (int32_t)(pix / cam.W);
+                    pi = (int32_t)(pix - (long long)r * cam.W);
+                    pj = part.row_begin + r * part.row_step;
+                    s_next = chunk * samples_per_item;
+                    s_end = min(cam.spp, s_next + samples_per_item);
+                    acc_r = acc_g = acc_b = 0ull;
+                    have_item = true;
+                    st.pixel = (uint32_t)pj * (uint32_t)cam.W + (uint32_t)pi;
+                }
+            }
+        }
+        if (!alive && !done) { // next sample of the item: camera.rs:224
+            st.sample = key.sample_offset + (uint32_t)s_next;
+            st.stage = 0u;
+            camera_ray(cam, pi, pj, st, ray);
+            thr = {1.f, 1.f, 1.f};
+            stage = 1;
+            s_next++;
+            n_samples++;
+            alive = true;
+        }
+        if (__ballot(alive) == 0ull) break;
+
+        if (alive) {
+            // ---- closest hit over the sphere list: hittable_list.rs:60-74 -----------------------
+            n_seg++;
+            const float ox = ray.o.x, oy = ray.o.y, oz = ray.o.z, dx = ray.d.x, dy = ray.d.y, dz = ray.d.z;
+            const float tmin = ray.tmin;
+            float best = INFINITY;
+            int32_t bpos = -1; // position in the narrow table
+            bool bfar = false;
+            for (int32_t k = 0; k < n_narrow_padded; k += kUnroll) {
+                // Phase 1, no branches: discriminants of kUnroll spheres (sphere.rs:29-34 with |d| = 1,
+                // disc = h^2 - (|oc|^2 - r^2)).  The addresses are the same for all lanes, so the
+                // geometry arrives through scalar loads and feeds the VALU as scalar operands.
+                float hv[kUnroll], dv[kUnroll];
+#pragma unroll
+                for (int32_t u = 0; u < kUnroll; ++u) {
+                    const float4 s = narrow_geom[k + u];
+                    const float ocx = s.x - ox, ocy = s.y - oy, ocz = s.z - oz;
+                    hv[u] = fmaf(ocz, dz, fmaf(ocy, dy, ocx * dx));
+                    const float q = fmaf(-ocz, ocz, fmaf(-ocy, ocy, fmaf(-ocx, ocx, s.w)));
+                    dv[u] = fmaf(hv[u], hv[u], q);
+                }
+                // Phase 2: roots only where the line meets the sphere (sphere.rs:36-48).
+#pragma unroll
+                for (int32_t u = 0; u < kUnroll; ++u) {
+                    if (dv[u] >= 0.f) {
+                        const float sq = fsqrt(dv[u]);
+                        const float t0 = hv[u] - sq;
+                        const bool far = !(t0 > tmin);
+                        const float t = far ? hv[u] + sq : t0;
+                        if (t > tmin && t < best) {
+                            best = t;
+                            bpos = k + u;
+                            bfar = far;
+                        }
+                    }
+                }
+            }
+            // Re-evaluate the winner from the perpendicular remainder |oc - h d|, which does not cancel.
+            int32_t bidx = -1; // position in the caller's list
+            F3 hp = {0.f, 0.f, 0.f}, hn = {0.f, 0.f, 0.f};
+            if (bpos >= 0) {
+                bidx = narrow_index[bpos];
+                const float4 s = geom32[bidx];
+                const F3 oc = {s.x - ox, s.y - oy, s.z - oz};
+                const float h = dot(oc, ray.d);
+                const F3 l = {fmaf(-h, dx, oc.x), fmaf(-h, dy, oc.y), fmaf(-h, dz, oc.z)};
+                const float disc = fmaxf(fmaf(s.w, s.w, -dot(l, l)), 0.f);
+                const float sq = fsqrt(disc);
+                best = bfar ? h + sq : h - sq;
+                hp = {fmaf(best, dx, ox), fmaf(best, dy, oy), fmaf(best, dz, oz)};
+                const float ir = rcp(s.w);
+                hn = {(hp.x - s.x) * ir, (hp.y - s.y) * ir, (hp.z - s.z) * ir}; // sphere.rs:52
+            }
+            for (int32_t wq = 0; wq < n_wide; ++wq) { // sphere.rs:28-57 in f64
+                const int32_t idx = wide_index[wq];
+                const double cx = geom64[4 * idx + 0], cy = geom64[4 * idx + 1], cz = geom64[4 * idx + 2];
+                const double rad = geom64[4 * idx + 3];
+                const double ocx = cx - (double)ox, ocy = cy - (double)oy, ocz = cz - (double)oz;
+                const double ddx = dx, ddy = dy, ddz = dz;
+                const double a = ddx * ddx + ddy * ddy + ddz * ddz;
+                const double h = ddx * ocx + ddy * ocy + ddz * ocz;
+                const double c = ocx * ocx + ocy * ocy + ocz * ocz - rad * rad;
+                const double disc = h * h - a * c;
+                if (disc >= 0.) {
+                    const double sq = sqrt(disc);
+                    double t = (h - sq) / a;
+                    if (!(t > (double)tmin)) t = (h + sq) / a;
+                    const float tf = (float)t;
+                    if (t > (double)tmin && (tf < best || (tf == best && idx < bidx))) {
+                        best = tf;
+                        bidx = idx;
+                        const double px = (double)ox + t * ddx, py = (double)oy + t * ddy, pz = (double)oz + t * ddz;
+                        hp = {(float)px, (float)py, (float)pz};
+                        hn = {(float)((px - cx) / rad), (float)((py - cy) / rad), (float)((pz - cz) / rad)};
+                    }
+                }
+            }
+
+            // ---- shade: camera.rs:270-281 ---------------------------------------------------------
+            F3 c = {0.f, 0.f, 0.f};
+            bool ended = true;
+            if (bidx < 0) { // sky
+                const float a = 0.5f * (dy + 1.0f);
+                const float w = 1.0f - a;
+                c = {thr.x * fmaf(a, 0.5f, w), thr.y * fmaf(a, 0.7f, w), thr.z * fmaf(a, 1.0f, w)};
+            } else {
+                const uint32_t mk = kind[bidx];
+                const float4 m = mat32[bidx];
+                const bool front = dot(ray.d, hn) < 0.f; // hittable.rs:16-22
+                const F3 n = front ? hn : F3{-hn.x, -hn.y, -hn.z};
+                st.stage = (uint32_t)stage;
+                F3 nd = {0.f, 0.f, 0.f};
+                bool scattered = false;
+                if (mk == DRAY_MAT_LAMBERTIAN) { // material.rs:46-56
+                    nd = n + random_unit_vector(st);
+                    if (fabsf(nd.x) < 1e-8f && fabsf(nd.y) < 1e-8f && fabsf(nd.z) < 1e-8f) nd = n;
+                    thr = {thr.x * m.x, thr.y * m.y, thr.z * m.z};
+                    scattered = true;
+                } else if (mk == DRAY_MAT_METAL) { // material.rs:73-80; reflect(d, n) is already unit
+                    const float dn = dot(ray.d, n);
+                    const F3 refl = {fmaf(-2.f * dn, n.x, dx), fmaf(-2.f * dn, n.y, dy), fmaf(-2.f * dn, n.z, dz)};
+                    const F3 ruv = random_unit_vector(st);
+                    nd = {fmaf(m.w, ruv.x, refl.x), fmaf(m.w, ruv.y, refl.y), fmaf(m.w, ruv.z, refl.z)};
+                    thr = {thr.x * m.x, thr.y * m.y, thr.z * m.z};
+                    scattered = dot(nd, n) > 0.f;
+                } else if (mk == DRAY_MAT_DIELECTRIC) { // material.rs:103-122
+                    const float ri = front ? rcp(m.w) : m.w;
+                    const float cos_theta = fminf(-dot(ray.d, n), 1.0f);
+                    const float sin_theta = fsqrt(fmaxf(fmaf(-cos_theta, cos_theta, 1.0f), 0.f));
+                    bool reflects = ri * sin_theta > 1.0f;
+                    if (!reflects) {
+                        uint32_t w[4];
+                        st.block(0, w);
+                        float r0 = (1.f - ri) * rcp(1.f + ri);
+                        r0 = r0 * r0;
+                        const float x = 1.f - cos_theta, x2 = x * x;
+                        reflects = fmaf(1.f - r0, x * x2 * x2, r0) > u01<float>(w[0]);
+                    }
+                    if (reflects) { // vec3.rs:97-102
+                        nd = {fmaf(2.f * cos_theta, n.x, dx), fmaf(2.f * cos_theta, n.y, dy), fmaf(2.f * cos_theta, n.z, dz)};
+                    } else { // vec3.rs:104-109
+                        const F3 perp = {ri * fmaf(cos_theta, n.x, dx), ri * fmaf(cos_theta, n.y, dy), ri * fmaf(cos_theta, n.z, dz)};
+                        const float kpar = -fsqrt(fabsf(1.0f - dot(perp, perp)));
+                        nd = {fmaf(kpar, n.x, perp.x), fmaf(kpar, n.y, perp.y), fmaf(kpar, n.z, perp.z)};
+                    }
+                    scattered = true;
+                }
+                if (scattered) {
+                    stage++;
+                    if (stage <= cam.max_depth) { // camera.rs:265: the next call would still have depth > 0
+                        ray.o = hp;
+                        set_dir(ray, nd);
+                        ended = false;
+                    }
+                }
+            }
+            if (ended) { // colors.rs:38
+                acc_r += to_fixed(c.x);
+                acc_g += to_fixed(c.y);
+                acc_b += to_fixed(c.z);
+                alive = false;
+            }
+        }
+    }
+
+    unsigned long long segs = n_seg, smps = n_samples;
+    for (int off = 32; off > 0; off >>= 1) {
+        segs += __shfl_down(segs, off, 64);
+        smps += __shfl_down(smps, off, 64);
+    }
+    if (lane == 0) {
+        atomicAdd(&counters->segments, segs);
+        atomicAdd(&counters->samples, smps);
+    }
+}
+
+// Adds the fixed-point sums into the caller's buffers and writes the packed colour: colors.rs:38-43.
+__global__ __launch_bounds__(256) void resolve_f32_kernel(int32_t W, int32_t spp, Partition part,
+                                                          const unsigned long long* __restrict__ accum,
+                                                          uint32_t* __restrict__ color, double* __restrict__ raw,
+                                                          int32_t* __restrict__ count) {
+    const long long npix = (long long)part.n_rows * W;
+    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npix) return;
+    const int32_t r = (int32_t)(p / W), i = (int32_t)(p - (long long)r * W);
+    const int32_t j = part.row_begin + r * part.row_step;
+    const size_t out = (size_t)(part.compact ? r : j) * (size_t)W + (size_t)i;
+    double s0 = (double)accum[0 * npix + p] * kFixInv;
+    double s1 = (double)accum[1 * npix + p] * kFixInv;
+    double s2 = (double)accum[2 * npix + p] * kFixInv;
+    if (raw) {
+        s0 += raw[3 * out + 0]; s1 += raw[3 * out + 1]; s2 += raw[3 * out + 2];
+        raw[3 * out + 0] = s0; raw[3 * out + 1] = s1; raw[3 * out + 2] = s2;
+    }
+    const int32_t cnt = (count ? count[out] : 0) + spp;
+    if (count) count[out] = cnt;
+    const double denom = cnt != 0 ? (double)cnt : 1.;
+    color[out] = pack_argb(s0 / denom, s1 / denom, s2 / denom);
+}
+
+} // namespace
+
+F32Plan plan_render_f32(const CamDev<float>& cam, const Partition& part, int32_t samples_per_item, int device) {
+    F32Plan plan{};
+    plan.block = 256;
+    int cus = 256, per_cu = 4;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+    int occ = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, render_f32_kernel, plan.block, 0) == hipSuccess && occ > 0)
+        per_cu = occ;
+    plan.grid = cus * per_cu;
+    const long long npix = (long long)part.n_rows * cam.W;
+    const long long lanes = (long long)plan.grid * plan.block;
+    int32_t s = samples_per_item;
+    if (s <= 0) { // aim at ~48 items per lane so that the last items of the launch cost little
+        long long want = ((long long)cam.spp * npix) / (lanes * 48 > 0 ? lanes * 48 : 1);
+        s = (int32_t)(want < 1 ? 1 : (want > 32 ? 32 : want));
+    }
+    if (s > cam.spp) s = cam.spp > 0 ? cam.spp : 1;
+    plan.samples_per_item = s;
+    plan.n_chunks = (cam.spp + s - 1) / s;
+    plan.accum_words = (size_t)3 * (size_t)(npix > 0 ? npix : 0);
+    const long long blocks_needed = (npix * plan.n_chunks + plan.block - 1) / plan.block;
+    if (blocks_needed < plan.grid) plan.grid = (int32_t)(blocks_needed > 0 ? blocks_needed : 1);
+    return plan;
+}
+
+hipError_t launch_render_f32(const CamDev<float>& cam, const SceneDev& scene, const Partition& part, const RngKey& key,
+                             const F32Plan& plan, unsigned long long* d_accum, DeviceCounters* d_counters,
+                             hipStream_t stream) {
+    const long long npix = (long long)part.n_rows * cam.W;
+    if (npix <= 0 || cam.spp <= 0) return hipSuccess;
+    const unsigned long long n_items = (unsigned long long)npix * (unsigned long long)plan.n_chunks;
+    hipLaunchKernelGGL(render_f32_kernel, dim3(plan.grid), dim3(plan.block), 0, stream, cam,
+                       (const float4*)scene.narrow_geom, scene.narrow_index, scene.n_narrow_padded, scene.wide_index,
+                       scene.n_wide, scene.geom64, (const float4*)scene.geom32, (const float4*)scene.mat32, scene.kind,
+                       part, key, plan.samples_per_item, plan.n_chunks, n_items, d_accum, d_counters);
+    return hipGetLastError();
+}
+
+hipError_t launch_resolve_f32(const CamDev<float>& cam, const Partition& part, const unsigned long long* d_accum,
+                              uint32_t* d_color, double* d_raw, int32_t* d_count, hipStream_t stream) {
+    const long long npix = (long long)part.n_rows * cam.W;
+    if (npix <= 0 || cam.spp <= 0) return hipSuccess;
+    const int block = 256;
+    const long long grid = (npix + block - 1) / block;
+    hipLaunchKernelGGL(resolve_f32_kernel, dim3((unsigned)grid), dim3(block), 0, stream, cam.W, cam.spp, part, d_accum,
+                       d_color, d_raw, d_count);
+    return hipGetLastError();
+}
+
+} // namespace dray

@@ -1,0 +1,298 @@
+// Reference-order render kernels for gfx950: every arithmetic step is written in
+// the operation order of the Rust reference so that the f64 instantiation can
+// be compared with the CPU oracle bit for bit.  Build with -ffp-contract=off.
+//
+// One thread owns one pixel and walks its samples in order (the reference's
+// sample-major loop, src/raytracer/camera.rs:217-219, visits a pixel's samples
+// in the same order; pixels do not interact).
+#pragma clang fp contract(off)
+
+#include "dray_device.h"
+#include "dray_internal.h"
+
+namespace dray {
+namespace {
+
+template <typename T>
+struct V3 {
+    T x, y, z;
+};
+
+// vec3.rs:131-257, element-wise, no fused operations.
+template <typename T> __device__ __forceinline__ V3<T> vadd(V3<T> a, V3<T> b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+template <typename T> __device__ __forceinline__ V3<T> vsub(V3<T> a, V3<T> b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+template <typename T> __device__ __forceinline__ V3<T> vmul(V3<T> a, V3<T> b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
+template <typename T> __device__ __forceinline__ V3<T> vscale(V3<T> a, T s) { return {a.x * s, a.y * s, a.z * s}; }
+template <typename T> __device__ __forceinline__ V3<T> vdiv(V3<T> a, T s) { return {a.x / s, a.y / s, a.z / s}; }
+template <typename T> __device__ __forceinline__ V3<T> vneg(V3<T> a) { return {-a.x, -a.y, -a.z}; }
+template <typename T> __device__ __forceinline__ T vdot(V3<T> a, V3<T> b) { return a.x * b.x + a.y * b.y + a.z * b.z; } // vec3.rs:64-66
+template <typename T> __device__ __forceinline__ T vlen2(V3<T> a) { return vdot(a, a); }
+template <typename T> __device__ __forceinline__ T rsqrt_exact(T x);
+template <> __device__ __forceinline__ double rsqrt_exact<double>(double x) { return sqrt(x); }
+template <> __device__ __forceinline__ float rsqrt_exact<float>(float x) { return sqrtf(x); }
+template <typename T> __device__ __forceinline__ T vsqrt(T x) { return rsqrt_exact<T>(x); }
+template <typename T> __device__ __forceinline__ V3<T> vunit(V3<T> a) { return vdiv(a, vsqrt(vlen2(a))); } // vec3.rs:120-122
+
+template <typename T> __device__ __forceinline__ V3<T> reflect(V3<T> v, V3<T> n) { // vec3.rs:97-102
+    V3<T> b = vscale(n, vdot(v, n));
+    return vsub(v, vscale(b, (T)2.0));
+}
+
+template <typename T> __device__ __forceinline__ V3<T> refract(V3<T> uv, V3<T> n, T eta) { // vec3.rs:104-109
+    T cos_theta = fmin(vdot(vneg(uv), n), (T)1.0);
+    V3<T> perp = vscale(vadd(uv, vscale(n, cos_theta)), eta);
+    T k = -(vsqrt(fabs((T)1.0 - vlen2(perp))));
+    return vadd(perp, vscale(n, k));
+}
+
+template <typename T> __device__ __forceinline__ T tiny_len2();
+template <> __device__ __forceinline__ double tiny_len2<double>() { return 1e-160; } // vec3.rs:80
+template <> __device__ __forceinline__ float tiny_len2<float>() { return 1e-30f; }   // f32 stand-in for 1e-160
+
+// vec3.rs:76-84.  Attempt a uses uniforms 4a, 4a+1, 4a+2 of the stage = words 0..2 of block a.
+template <typename T> __device__ __forceinline__ V3<T> random_unit_vector(const Stream& st) {
+    for (uint32_t a = 0;; ++a) {
+        uint32_t w[4];
+        st.block(a, w);
+        V3<T> p;
+        p.x = (T)-1. + ((T)1. - (T)-1.) * u01<T>(w[0]); // prelude.rs:27-30
+        p.y = (T)-1. + ((T)1. - (T)-1.) * u01<T>(w[1]);
+        p.z = (T)-1. + ((T)1. - (T)-1.) * u01<T>(w[2]);
+        T lensq = vlen2(p);
+        if (tiny_len2<T>() <= lensq && lensq <= (T)1.) return vdiv(p, vsqrt(lensq));
+    }
+}
+
+template <typename T> struct Hit {
+    V3<T> p, normal;
+    T t;
+    bool front_face;
+    int32_t index;
+};
+
+// hittable_list.rs:60-74 around sphere.rs:28-57: insertion order, shrinking upper bound.
+template <typename T>
+__device__ __forceinline__ bool list_hit(const T* __restrict__ geom, int32_t n, V3<T> ro, V3<T> rd, Hit<T>& rec) {
+    bool hit_anything = false;
+    T closest = (T)INFINITY;
+    const T tmin = (T)0.001;
+    for (int32_t k = 0; k < n; ++k) {
+        const V3<T> center = {geom[4 * k + 0], geom[4 * k + 1], geom[4 * k + 2]};
+        const T radius = geom[4 * k + 3];
+        V3<T> oc = vsub(center, ro);
+        T a = vlen2(rd);
+        T h = vdot(rd, oc);
+        T c = vlen2(oc) - radius * radius;
+        T discriminant = h * h - a * c;
+        if (discriminant < (T)0.) continue;
+        T sqrtd = vsqrt(discriminant);
+        T root = (h - sqrtd) / a;
+        if (!(tmin < root && root < closest)) { // interval.rs:28-30, strict
+            root = (h + sqrtd) / a;
+            if (!(tmin < root && root < closest)) continue;
+        }
+        rec.t = root;
+        rec.p = vadd(ro, vscale(rd, root)); // ray.rs:17-19
+        V3<T> on = vdiv(vsub(rec.p, center), radius);
+        rec.front_face = vdot(rd, on) < (T)0.; // hittable.rs:16-22
+        rec.normal = rec.front_face ? on : vscale(on, (T)-1.);
+        rec.index = k;
+        hit_anything = true;
+        closest = root;
+    }
+    return hit_anything;
+}
+
+template <typename T> __device__ __forceinline__ T reflectance(T cosine, T ri) { // material.rs:93-98
+    T r0 = ((T)1. - ri) / ((T)1. + ri);
+    r0 = r0 * r0;
+    T x = (T)1. - cosine;
+    T x2 = x * x;
+    T x5 = x * (x2 * x2); // powi(5)
+    return r0 + ((T)1. - r0) * x5;
+}
+
+// material.rs scatter of the four material kinds.  Returns false when the ray is absorbed.
+template <typename T>
+__device__ __forceinline__ bool scatter(uint32_t kind, const T* __restrict__ mat, V3<T> rd, const Hit<T>& rec,
+                                        const Stream& st, V3<T>& sd) {
+    if (kind == DRAY_MAT_LAMBERTIAN) { // material.rs:46-56
+        V3<T> dir = vadd(rec.normal, random_unit_vector<T>(st));
+        const T s = (T)1e-8; // vec3.rs:42-45
+        if (fabs(dir.x) < s && fabs(dir.y) < s && fabs(dir.z) < s) dir = rec.normal;
+        sd = dir;
+        return true;
+    }
+    if (kind == DRAY_MAT_METAL) { // material.rs:73-80
+        V3<T> refl = reflect(rd, rec.normal);
+        refl = vadd(vunit(refl), vscale(random_unit_vector<T>(st), mat[3]));
+        sd = refl;
+        return vdot(sd, rec.normal) > (T)0.;
+    }
+    if (kind == DRAY_MAT_DIELECTRIC) { // material.rs:103-122
+        const T ior = mat[3];
+        T ri = rec.front_face ? (T)1.0 / ior : ior;
+        V3<T> ud = vunit(rd);
+        T cos_theta = fmin(vdot(vneg(ud), rec.normal), (T)1.0);
+        T sin_theta = vsqrt((T)1.0 - cos_theta * cos_theta);
+        bool reflects = ri * sin_theta > (T)1.0;
+        if (!reflects) { // the uniform is drawn only when refraction is possible
+            uint32_t w[4];
+            st.block(0, w);
+            reflects = reflectance(cos_theta, ri) > u01<T>(w[0]);
+        }
+        sd = reflects ? reflect(ud, rec.normal) : refract(ud, rec.normal, ri);
+        return true;
+    }
+    return false; // material.rs:13-19
+}
+
+// camera.rs:238-262
+template <typename T>
+__device__ __forceinline__ void get_ray(const CamDev<T>& cam, int32_t i, int32_t j, const Stream& st, V3<T>& ro,
+                                        V3<T>& rd) {
+    uint32_t w[4];
+    st.block(0, w);
+    const T ox = u01<T>(w[0]) - (T)0.5, oy = u01<T>(w[1]) - (T)0.5;
+    const V3<T> p00 = {cam.p00[0], cam.p00[1], cam.p00[2]};
+    const V3<T> du = {cam.du[0], cam.du[1], cam.du[2]}, dv = {cam.dv[0], cam.dv[1], cam.dv[2]};
+    const V3<T> center = {cam.center[0], cam.center[1], cam.center[2]};
+    V3<T> ps = vadd(vadd(p00, vscale(du, (T)i + ox)), vscale(dv, (T)j + oy));
+    if (!cam.defocus) {
+        ro = center;
+    } else {
+        // vec3.rs:111-118; attempt m uses uniforms 2+2m, 3+2m of stage 0
+        T px, py;
+        for (uint32_t m = 0;; ++m) {
+            const uint32_t d0 = 2u + 2u * m;
+            if (m > 0 && (d0 & 3u) == 0u) st.block(d0 >> 2, w);
+            px = (T)-1. + ((T)1. - (T)-1.) * u01<T>(w[d0 & 3u]);
+            py = (T)-1. + ((T)1. - (T)-1.) * u01<T>(w[(d0 & 3u) + 1u]);
+            if (px * px + py * py + (T)0. * (T)0. < (T)1.) break;
+        }
+        const V3<T> ddu = {cam.ddu[0], cam.ddu[1], cam.ddu[2]}, ddv = {cam.ddv[0], cam.ddv[1], cam.ddv[2]};
+        ro = vadd(vadd(center, vscale(ddu, px)), vscale(ddv, py));
+    }
+    rd = vsub(ps, ro);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void render_ref_kernel(CamDev<T> cam, const T* __restrict__ geom,
+                                                         const T* __restrict__ mat, const uint32_t* __restrict__ kind,
+                                                         int32_t n, Partition part, RngKey key, uint32_t flags,
+                                                         uint32_t* __restrict__ color, double* __restrict__ raw,
+                                                         int32_t* __restrict__ count, DeviceCounters* counters) {
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)part.n_rows * cam.W;
+    unsigned long long my_segments = 0, my_samples = 0;
+    if (tid < total) {
+        const int32_t r = (int32_t)(tid / cam.W), i = (int32_t)(tid % cam.W);
+        const int32_t j = part.row_begin + r * part.row_step;
+        const size_t out = (size_t)(part.compact ? r : j) * (size_t)cam.W + (size_t)i;
+        const bool iterative = (flags & DRAY_FLAG_ITERATIVE_PRODUCT) != 0;
+
+        double acc[3] = {0., 0., 0.};
+        if (raw) { acc[0] = raw[3 * out + 0]; acc[1] = raw[3 * out + 1]; acc[2] = raw[3 * out + 2]; }
+
+        uint32_t stack[kExactMaxDepth]; // spheres whose albedo multiplies the sample, outermost first
+
+        for (int32_t s = 0; s < cam.spp; ++s) {
+            Stream st = {key.k0, key.k1, (uint32_t)j * (uint32_t)cam.W + (uint32_t)i, key.sample_offset + (uint32_t)s, 0u};
+            V3<T> ro, rd;
+            get_ray(cam, i, j, st, ro, rd);
+
+            V3<T> att = {(T)1., (T)1., (T)1.}; // camera.rs:26 (iterative form)
+            V3<T> c = {(T)0., (T)0., (T)0.};
+            int32_t depth = cam.max_depth, sp = 0;
+            for (;;) {
+                if (depth <= 0) { c = {(T)0., (T)0., (T)0.}; break; } // camera.rs:265-267 / :120-123
+                Hit<T> rec;
+                my_segments++;
+                if (list_hit<T>(geom, n, ro, rd, rec)) { // camera.rs:270
+                    st.stage = (uint32_t)(cam.max_depth - depth + 1);
+                    V3<T> sd;
+                    if (scatter<T>(kind[rec.index], mat + 4 * rec.index, rd, rec, st, sd)) {
+                        const uint32_t k = kind[rec.index];
+                        if (iterative) {
+                            V3<T> a = k == DRAY_MAT_DIELECTRIC ? V3<T>{(T)1., (T)1., (T)1.}
+                                                               : V3<T>{mat[4 * rec.index], mat[4 * rec.index + 1], mat[4 * rec.index + 2]};
+                            att = vmul(att, a); // camera.rs:130
+                        } else if (k != DRAY_MAT_DIELECTRIC) {
+                            stack[sp++] = (uint32_t)rec.index; // a product with (1,1,1) is exact, so glass is skipped
+                        }
+                        ro = rec.p;
+                        rd = sd;
+                        depth -= 1;
+                        continue;
+                    }
+                    c = {(T)0., (T)0., (T)0.}; // camera.rs:276
+                    break;
+                }
+                V3<T> ud = vunit(rd); // camera.rs:279-281
+                T a = (T)0.5 * (ud.y + (T)1.0);
+                c = vadd(vscale(V3<T>{(T)1.0, (T)1.0, (T)1.0}, (T)1.0 - a), vscale(V3<T>{(T)0.5, (T)0.7, (T)1.0}, a));
+                break;
+            }
+            if (iterative) {
+                c = vmul(att, c); // camera.rs:121,135,142
+            } else {
+                while (sp > 0) { // camera.rs:274, innermost product first
+                    const uint32_t q = stack[--sp];
+                    c = vmul(V3<T>{mat[4 * q], mat[4 * q + 1], mat[4 * q + 2]}, c);
+                }
+            }
+            // camera.rs:223-225 (0 + sample) then colors.rs:38
+            acc[0] += (double)((T)0. + c.x);
+            acc[1] += (double)((T)0. + c.y);
+            acc[2] += (double)((T)0. + c.z);
+            my_samples++;
+        }
+
+        int32_t cnt = (count ? count[out] : 0) + cam.spp; // colors.rs:39
+        const double denom = cnt != 0 ? (double)cnt : 1.; // colors.rs:40
+        color[out] = pack_argb(acc[0] / denom, acc[1] / denom, acc[2] / denom);
+        if (raw) { raw[3 * out + 0] = acc[0]; raw[3 * out + 1] = acc[1]; raw[3 * out + 2] = acc[2]; }
+        if (count) count[out] = cnt;
+    }
+    // one atomic per wave
+    for (int off = 32; off > 0; off >>= 1) {
+        my_segments += __shfl_down(my_segments, off, 64);
+        my_samples += __shfl_down(my_samples, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0 && counters) {
+        atomicAdd(&counters->segments, my_segments);
+        atomicAdd(&counters->samples, my_samples);
+    }
+}
+
+template <typename T>
+hipError_t launch_ref(const CamDev<T>& cam, const T* geom, const T* mat, const SceneDev& scene, const Partition& part,
+                      const RngKey& key, uint32_t flags, uint32_t* d_color, double* d_raw, int32_t* d_count,
+                      DeviceCounters* d_counters, hipStream_t stream) {
+    const long long total = (long long)part.n_rows * cam.W;
+    if (total <= 0) return hipSuccess;
+    const int block = 256;
+    const long long grid = (total + block - 1) / block;
+    if (grid > 0x7fffffffLL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(render_ref_kernel<T>, dim3((unsigned)grid), dim3(block), 0, stream, cam, geom, mat, scene.kind,
+                       scene.n, part, key, flags, d_color, d_raw, d_count, d_counters);
+    return hipGetLastError();
+}
+
+} // namespace
+
+hipError_t launch_render_ref_f64(const CamDev<double>& cam, const SceneDev& scene, const Partition& part,
+                                 const RngKey& key, uint32_t flags, uint32_t* d_color, double* d_raw, int32_t* d_count,
+                                 DeviceCounters* d_counters, hipStream_t stream) {
+    return launch_ref<double>(cam, scene.geom64, scene.mat64, scene, part, key, flags, d_color, d_raw, d_count,
+                              d_counters, stream);
+}
+
+hipError_t launch_render_ref_f32(const CamDev<float>& cam, const SceneDev& scene, const Partition& part,
+                                 const RngKey& key, uint32_t flags, uint32_t* d_color, double* d_raw, int32_t* d_count,
+                                 DeviceCounters* d_counters, hipStream_t stream) {
+    return launch_ref<float>(cam, scene.geom32, scene.mat32, scene, part, key, flags, d_color, d_raw, d_count,
+                             d_counters, stream);
+}
+
+} // namespace dray

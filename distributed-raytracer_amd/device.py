@@ -1,0 +1,100 @@
+"""Device-resident rendering: scene tables and frame buffers stay in HBM.
+
+Thin wrappers over ``dray_scene_create`` / ``dray_render_device`` (include/dray.h)
+that take torch tensors for the buffers.  torch is used for device memory and
+streams only.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _ffi
+from .raytracer import Camera, flatten_world
+
+
+class DeviceScene:
+    """The sphere list of a HittableList uploaded to one GPU."""
+
+    def __init__(self, world, device=0):
+        self.spheres = flatten_world(world)
+        self.device = int(device)
+        h = C.c_void_p()
+        _ffi.check(_ffi.lib().dray_scene_create(self.spheres.ctypes.data if len(self.spheres) else None,
+                                                len(self.spheres), self.device, C.byref(h)))
+        self._h = h
+
+    @property
+    def handle(self):
+        if self._h is None:
+            raise _ffi.DrayError(_ffi.ERR_INVALID_ARG, "scene already destroyed")
+        return self._h
+
+    def __len__(self):
+        return len(self.spheres)
+
+    def close(self):
+        if self._h is not None:
+            _ffi.lib().dray_scene_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _ptr(t, dtype, name):
+    import torch
+    if t is None:
+        return None, 0
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.is_contiguous() and t.dtype == dtype):
+        raise _ffi.DrayError(_ffi.ERR_INVALID_ARG, "%s must be a contiguous CUDA tensor of %s" % (name, dtype))
+    return t.data_ptr(), t.numel()
+
+
+def alloc_buffers(cam: Camera, device, rows=None, with_raw=True):
+    """Zeroed colour / running-sum / count buffers for ``rows`` scanlines (default: the whole image).
+
+    The colour buffer is int32 holding the reference's u32 ARGB bit pattern (colors.rs:42)."""
+    import torch
+    cam.initialize()
+    n_rows = cam.image_height if rows is None else rows
+    dev = torch.device("cuda", device)
+    color = torch.zeros((n_rows, cam.image_width), dtype=torch.int32, device=dev)
+    raw = torch.zeros((n_rows, cam.image_width, 3), dtype=torch.float64, device=dev) if with_raw else None
+    count = torch.zeros((n_rows, cam.image_width), dtype=torch.int32, device=dev) if with_raw else None
+    return color, raw, count
+
+
+def render_device(cam: Camera, scene: DeviceScene, color, raw=None, count=None, stream=None, want_stats=True,
+                  **opt_overrides):
+    """Camera::render with device buffers.  Returns dray_stats (or None when want_stats is False: then the
+    call only enqueues work on ``stream``)."""
+    import torch
+    pc, nc = _ptr(color, torch.int32, "color")
+    pr, nr = _ptr(raw, torch.float64, "raw")
+    pn, nn = _ptr(count, torch.int32, "count")
+    buf_len = nc
+    if raw is not None:
+        buf_len = min(buf_len, nr // 3)
+    if count is not None:
+        buf_len = min(buf_len, nn)
+    if color.device.index != scene.device:
+        raise _ffi.DrayError(_ffi.ERR_INVALID_ARG, "buffers and scene live on different devices")
+    if stream is None:
+        stream = torch.cuda.current_stream(color.device)
+    pod = cam.pod()
+    opts = cam.opts(**opt_overrides)
+    opts.device = scene.device
+    st = _ffi.Stats() if want_stats else None
+    rc = _ffi.lib().dray_render_device(C.byref(pod), scene.handle, pc, pr, pn, buf_len, C.byref(opts),
+                                       C.c_void_p(stream.cuda_stream), C.byref(st) if want_stats else None)
+    _ffi.check(rc)
+    cam.last_stats = st
+    return st
+
+
+def color_to_numpy(color):
+    """int32 device colour buffer -> uint32 numpy array with the reference's ARGB packing."""
+    return color.detach().cpu().numpy().view(np.uint32)

@@ -1,0 +1,259 @@
+"""Host-side mirror of the reference's scene / camera API for the render path.
+
+Names, argument meaning and error behaviour follow ``src/raytracer`` of the
+reference (Rust): ``Sphere::new`` (sphere.rs:13), ``HittableList`` (hittable_list.rs:11-40),
+``Lambertian/Metal/Dialectric::new`` (material.rs:39,66,89), ``Camera`` with its ten
+public fields (camera.rs:41-54), ``Camera::new`` (:147) and ``Camera::render`` (:208).
+Only ``render`` does work: it flattens the scene and calls the HIP library through
+its C ABI.  The Rust reference cannot be compiled in this environment, so this
+Python mirror (and the C++ one in include/dray.hpp) is what the tests drive.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import (FLAG_COMPACT_ROWS, FLAG_ITERATIVE_PRODUCT, MAT_DEFAULT, MAT_DIELECTRIC, MAT_LAMBERTIAN, MAT_METAL,
+                   MODE_F32, MODE_F32_PLAIN, MODE_F64, DrayError)
+
+
+def _v3(v):
+    v = tuple(float(x) for x in v)
+    if len(v) != 3:
+        raise ValueError("expected 3 components")
+    return v
+
+
+# ------------------------------------------------------------------ materials --
+
+class Material:
+    kind = MAT_DEFAULT
+    albedo = (0.0, 0.0, 0.0)
+    param = 0.0
+
+
+class DefaultMaterial(Material):
+    """Absorbs every ray (material.rs:10-19)."""
+
+
+class Lambertian(Material):
+    kind = MAT_LAMBERTIAN
+
+    def __init__(self, albedo):
+        self.albedo = _v3(albedo)
+
+
+class Metal(Material):
+    kind = MAT_METAL
+
+    def __init__(self, albedo, fuzz):
+        self.albedo = _v3(albedo)
+        self.param = float(fuzz) if fuzz < 1.0 else 1.0  # material.rs:67
+
+
+class Dialectric(Material):  # spelling as in the reference (material.rs:84)
+    kind = MAT_DIELECTRIC
+
+    def __init__(self, refraction_index):
+        self.param = float(refraction_index)
+
+
+# ------------------------------------------------------------------- hittables --
+
+class Hittable:
+    """Anything that can be put into a HittableList (hittable.rs:25-28)."""
+
+    def flatten(self, out):
+        raise DrayError(_ffi.ERR_UNSUPPORTED, "%s has no GPU representation" % type(self).__name__)
+
+
+class Sphere(Hittable):
+    def __init__(self, center, radius, mat):
+        self._center = _v3(center)
+        self._radius = max(float(radius), 0.0)  # sphere.rs:14
+        self._mat = mat
+
+    def center(self):
+        return self._center
+
+    def radius(self):
+        return self._radius
+
+    def flatten(self, out):
+        if not isinstance(self._mat, Material):
+            raise DrayError(_ffi.ERR_UNSUPPORTED, "unknown material %r" % (self._mat,))
+        out.append((self._center, self._radius, self._mat.kind, 0, self._mat.albedo, self._mat.param))
+
+
+class HittableList(Hittable):
+    def __init__(self, objects=None):
+        self.objects = list(objects) if objects is not None else []
+
+    def add(self, obj):
+        self.objects.append(obj)
+
+    def clear(self):
+        self.objects.clear()
+
+    def len(self):
+        return len(self.objects)
+
+    def __len__(self):
+        return len(self.objects)
+
+    def __getitem__(self, i):
+        return self.objects[i]
+
+    def flatten(self, out):
+        for o in self.objects:  # insertion order is the tie-break order (hittable_list.rs:65-70)
+            if not isinstance(o, Hittable):
+                raise DrayError(_ffi.ERR_UNSUPPORTED, "unknown hittable %r" % (o,))
+            o.flatten(out)
+
+
+def flatten_world(world):
+    """World -> numpy array of dray_sphere records, or pass an already flat array through."""
+    if isinstance(world, np.ndarray):
+        return np.ascontiguousarray(world, dtype=_ffi.SPHERE_DTYPE)
+    rows = []
+    world.flatten(rows)
+    return np.array(rows, dtype=_ffi.SPHERE_DTYPE) if rows else np.zeros(0, dtype=_ffi.SPHERE_DTYPE)
+
+
+# ---------------------------------------------------------------------- camera --
+
+class Camera:
+    """Public fields and defaults of the reference camera (camera.rs:41-54,147-163)."""
+
+    def __init__(self):
+        self.aspect_ratio = 1.0
+        self.image_width = 100
+        self.samples_per_pixel = 10
+        self.max_depth = 10
+        self.vfov = 90.0
+        self.lookfrom = (0.0, 0.0, 0.0)
+        self.lookat = (0.0, 0.0, -1.0)
+        self.vup = (0.0, 1.0, 0.0)
+        self.defocus_angle = 0.0
+        self.focus_dist = 10.0
+        # backend options (not in the reference): see dray_opts in include/dray.h
+        self.seed = 1
+        self.mode = MODE_F32
+        self.flags = 0
+        self.sample_offset = 0
+        self.device = -1
+        self.last_stats = None
+
+    @classmethod
+    def new(cls):
+        return cls()
+
+    def pod(self):
+        c = _ffi.CameraPOD()
+        c.aspect_ratio = float(self.aspect_ratio)
+        c.image_width = int(self.image_width)
+        c.samples_per_pixel = int(self.samples_per_pixel)
+        c.max_depth = int(self.max_depth)
+        c.vfov = float(self.vfov)
+        c.lookfrom = _ffi.D3(*_v3(self.lookfrom))
+        c.lookat = _ffi.D3(*_v3(self.lookat))
+        c.vup = _ffi.D3(*_v3(self.vup))
+        c.defocus_angle = float(self.defocus_angle)
+        c.focus_dist = float(self.focus_dist)
+        return c
+
+    def initialize(self):
+        """Camera::initialize (camera.rs:169-206), computed by the library on the host."""
+        d = _ffi.CameraDerivedPOD()
+        pod = self.pod()
+        _ffi.check(_ffi.lib().dray_camera_initialize(C.byref(pod), C.byref(d)))
+        self.image_height = d.image_height
+        self.pixel_samples_scale = d.pixel_samples_scale
+        self.derived = d
+        return d
+
+    def opts(self, **kw):
+        base = dict(seed=self.seed, mode=self.mode, flags=self.flags, sample_offset=self.sample_offset,
+                    device=self.device)
+        base.update(kw)
+        return _ffi.default_opts(**base)
+
+    def render(self, world, window, color_buffer, raw_buffer, count_buffer, **opt_overrides):
+        """Camera::render (camera.rs:208-236) on the GPU.
+
+        color_buffer: uint32[>= W*H]; raw_buffer: float64[>= W*H, 3] or None; count_buffer: int32[>= W*H] or None.
+        The buffers are accumulated into, never cleared (colors.rs:38-39).  ``window`` (may be None) gets one
+        ``update_with_buffer(color_buffer, W, H)`` per call instead of one per pixel sample (colors.rs:44).
+        Raises DrayError where the Rust binding would return an io::Error.
+        """
+        spheres = flatten_world(world)
+        self.initialize()
+        for name, buf, dt in (("color_buffer", color_buffer, np.uint32), ("raw_buffer", raw_buffer, np.float64),
+                              ("count_buffer", count_buffer, np.int32)):
+            if buf is None:
+                if name == "color_buffer":
+                    raise DrayError(_ffi.ERR_INVALID_ARG, "color_buffer is required")
+                continue
+            if not (isinstance(buf, np.ndarray) and buf.dtype == dt and buf.flags.c_contiguous and buf.flags.writeable):
+                raise DrayError(_ffi.ERR_INVALID_ARG, "%s must be a writable contiguous %s array" % (name, dt.__name__))
+        buf_len = color_buffer.size
+        if raw_buffer is not None and raw_buffer.size // 3 < buf_len:
+            buf_len = raw_buffer.size // 3
+        if count_buffer is not None and count_buffer.size < buf_len:
+            buf_len = count_buffer.size
+        pod = self.pod()
+        opts = self.opts(**opt_overrides)
+        st = _ffi.Stats()
+        rc = _ffi.lib().dray_render(
+            C.byref(pod), spheres.ctypes.data if len(spheres) else None, len(spheres), color_buffer.ctypes.data,
+            raw_buffer.ctypes.data if raw_buffer is not None else None,
+            count_buffer.ctypes.data if count_buffer is not None else None, buf_len, C.byref(opts), C.byref(st))
+        _ffi.check(rc)
+        self.last_stats = st
+        if window is not None:
+            window.update_with_buffer(color_buffer, self.image_width, self.image_height)
+        return None  # Ok(())
+
+
+# --------------------------------------------------------------- scene recipes --
+
+def scene_final(seed=1):
+    """Sphere list of the reference's local binary (main.rs:13-50), uniforms from the Philox stream of ``seed``."""
+    arr = np.zeros(600, dtype=_ffi.SPHERE_DTYPE)
+    n = _ffi.lib().dray_scene_final(seed, arr.ctypes.data, len(arr))
+    if n < 0:
+        _ffi.check(n)
+    return arr[:n].copy()
+
+
+def scene_three_spheres():
+    arr = np.zeros(4, dtype=_ffi.SPHERE_DTYPE)
+    n = _ffi.lib().dray_scene_three_spheres(arr.ctypes.data, len(arr))
+    if n < 0:
+        _ffi.check(n)
+    return arr[:n].copy()
+
+
+def camera_final(width=1200, spp=500, depth=50):
+    """Camera of the reference's local binary (main.rs:55-66)."""
+    cam = Camera()
+    cam.aspect_ratio = 16.0 / 9.0
+    cam.image_width = width
+    cam.samples_per_pixel = spp
+    cam.max_depth = depth
+    cam.vfov = 20.0
+    cam.lookfrom = (13.0, 2.0, 3.0)
+    cam.lookat = (0.0, 0.0, 0.0)
+    cam.vup = (0.0, 1.0, 0.0)
+    cam.defocus_angle = 0.6
+    cam.focus_dist = 10.0
+    return cam
+
+
+def camera_three_spheres(width=400, spp=10, depth=10):
+    cam = Camera()
+    cam.aspect_ratio = 16.0 / 9.0
+    cam.image_width = width
+    cam.samples_per_pixel = spp
+    cam.max_depth = depth
+    return cam

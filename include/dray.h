@@ -1,0 +1,177 @@
+/*
+ * dray.h -- C ABI of libdray_hip.so, the MI355X (gfx950) backend for the path
+ * tracer's per-pixel render path.
+ *
+ * The library replaces the body of the reference's
+ *     Camera::render(&mut self, world, window, color_buffer, raw_buffer, count_buffer)
+ * (src/raytracer/camera.rs:208-236): camera set-up, the sample loop, ray_color,
+ * the sphere-list intersection, the material scatter and the colour write.
+ * A Rust `-sys` crate binds exactly these symbols; nothing here uses C++ or
+ * torch types.  All functions return DRAY_OK (0) or a negative dray_status;
+ * nothing throws or unwinds across this boundary.
+ *
+ * Randomness: the reference draws from an OS-seeded generator
+ * (src/raytracer/prelude.rs:22-25).  This backend draws every uniform from a
+ * Philox4x32-10 stream: key = seed, counter = (pixel index j*W+i, sample index,
+ * stage, block).  Stage 0 is the camera ray (uniforms 0,1 = pixel offsets,
+ * aperture attempt m = uniforms 2+2m, 3+2m); stage k >= 1 is the scatter after
+ * the k-th intersection (unit-vector attempt a = uniforms 4a..4a+2, dielectric
+ * reflect/refract choice = uniform 0).  Uniform n of a stage is word n%4 of
+ * block n/4, mapped to [0,1) as (word >> 8) * 2^-24.  The image therefore
+ * depends only on (scene, camera, seed, sample_offset), never on the GPU
+ * count, the partition or the scheduling.
+ */
+#ifndef DRAY_H
+#define DRAY_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum dray_status {
+    DRAY_OK = 0,
+    DRAY_ERR_INVALID_ARG = -1,
+    DRAY_ERR_BUFFER_TOO_SMALL = -2,
+    DRAY_ERR_UNSUPPORTED = -3,
+    DRAY_ERR_NO_DEVICE = -4,
+    DRAY_ERR_HIP = -5,
+    DRAY_ERR_INTERNAL = -6
+} dray_status;
+
+/* The ten public camera fields, src/raytracer/camera.rs:42-53, same order. */
+typedef struct dray_camera {
+    double aspect_ratio;
+    int32_t image_width;
+    int32_t samples_per_pixel;
+    int32_t max_depth;
+    int32_t _pad;
+    double vfov;
+    double lookfrom[3];
+    double lookat[3];
+    double vup[3];
+    double defocus_angle;
+    double focus_dist;
+} dray_camera;
+
+/* The private camera fields computed by Camera::initialize, camera.rs:55-65,169-206. */
+typedef struct dray_camera_derived {
+    int32_t image_height;
+    int32_t _pad;
+    double pixel_samples_scale;
+    double center[3];
+    double pixel00_loc[3];
+    double pixel_delta_u[3];
+    double pixel_delta_v[3];
+    double u[3], v[3], w[3];
+    double defocus_disk_u[3];
+    double defocus_disk_v[3];
+} dray_camera_derived;
+
+/* Material kinds: material.rs:10-19 (absorbs everything), :33-57, :59-81, :83-123. */
+enum { DRAY_MAT_DEFAULT = 0, DRAY_MAT_LAMBERTIAN = 1, DRAY_MAT_METAL = 2, DRAY_MAT_DIELECTRIC = 3 };
+
+/* One Sphere (sphere.rs:6-10) with its material flattened in.  radius is used as
+ * max(radius, 0) (sphere.rs:14); a metal's fuzz as min(fuzz, 1) (material.rs:67).
+ * Order in the array = insertion order of HittableList::add (hittable_list.rs:30-32):
+ * on equal hit distance the earlier sphere wins (hittable_list.rs:65-70). */
+typedef struct dray_sphere {
+    double center[3];
+    double radius;
+    uint32_t kind;
+    uint32_t _pad;
+    double albedo[3];   /* Lambertian / Metal */
+    double fuzz_or_ior; /* Metal: fuzz; Dialectric: refraction index */
+} dray_sphere;
+
+/* Arithmetic of the render. */
+enum {
+    DRAY_MODE_F64 = 0,      /* f64, operation order of the reference: the parity mode */
+    DRAY_MODE_F32 = 1,      /* f32 throughput kernel (large spheres are intersected in f64) */
+    DRAY_MODE_F32_PLAIN = 2 /* f32, operation order of the reference, no restructuring (A/B baseline) */
+};
+
+enum {
+    /* f64 / f32-plain: multiply attenuations left to right as ray_color_iteration does
+     * (camera.rs:118-144) instead of right to left as the recursion does (camera.rs:264-282). */
+    DRAY_FLAG_ITERATIVE_PRODUCT = 1u,
+    /* Rendered rows are stored back to back: row j goes to slab row (j-row_begin)/row_step.
+     * Without it row j is stored at j*image_width as the reference does (colors.rs:37). */
+    DRAY_FLAG_COMPACT_ROWS = 2u
+};
+
+typedef struct dray_opts {
+    uint64_t seed;
+    uint32_t mode;
+    uint32_t flags;
+    uint32_t sample_offset;   /* index of the first sample's stream; a later call continuing the
+                                 same buffers passes the number of samples already accumulated */
+    int32_t device;           /* HIP device ordinal, -1 = the current device */
+    int32_t row_begin;        /* scanline partition: rows row_begin, row_begin+row_step, ... */
+    int32_t row_step;         /* 0 is read as 1 */
+    int32_t samples_per_item; /* f32 mode: samples per work item, 0 = library default */
+    int32_t _reserved;
+} dray_opts;
+
+typedef struct dray_stats {
+    uint64_t segments;  /* path segments = world.hit calls (camera.rs:270) */
+    uint64_t samples;   /* get_ray + ray_color pairs (camera.rs:224-225) */
+    double kernel_ms;   /* trace kernel, HIP events on the launch stream */
+    double resolve_ms;  /* accumulate / gamma / pack kernel */
+    double total_ms;    /* whole call, host clock */
+    int32_t image_height;
+    int32_t rows_rendered;
+    int32_t n_spheres;
+    int32_t n_wide_spheres; /* spheres routed to the f64 intersection in DRAY_MODE_F32 */
+} dray_stats;
+
+typedef struct dray_scene dray_scene; /* device-resident sphere tables + workspace */
+
+/* ---- housekeeping --------------------------------------------------------- */
+const char* dray_version(void);
+const char* dray_strerror(int status);
+/* Number of HIP devices, or a negative dray_status. */
+int dray_device_count(void);
+void dray_opts_default(dray_opts* opts);
+
+/* ---- host-side camera maths (no GPU needed) ------------------------------ */
+/* Camera::new, camera.rs:147-163. */
+void dray_camera_default(dray_camera* cam);
+/* Camera::initialize, camera.rs:169-206, in f64 on the host. */
+int dray_camera_initialize(const dray_camera* cam, dray_camera_derived* out);
+
+/* ---- the drop-in render call --------------------------------------------- */
+/* Camera::render, camera.rs:208-236, with host buffers as the reference has them:
+ *   color  len >= buf_len, ARGB 0xFFrrggbb at j*W+i             (colors.rs:42-43)
+ *   raw    3 f64 per pixel, running colour sum, added to        (colors.rs:38); may be NULL
+ *   count  running sample count per pixel, added to             (colors.rs:39); may be NULL
+ * buf_len is the length of each buffer in pixels and must be >= W*image_height; entries past
+ * the rendered rows are left untouched (the reference's caller allocates W*W, main.rs:69-73).
+ * Blocking.  The window refresh of colors.rs:44 is the caller's business. */
+int dray_render(const dray_camera* cam, const dray_sphere* spheres, size_t n_spheres, uint32_t* color, double* raw,
+                int32_t* count, size_t buf_len, const dray_opts* opts, dray_stats* stats);
+
+/* ---- device-resident variant (buffers already in HBM) --------------------- */
+/* Upload the sphere list of a HittableList (hittable_list.rs:7-9) to `device`. */
+int dray_scene_create(const dray_sphere* spheres, size_t n_spheres, int32_t device, dray_scene** out);
+void dray_scene_destroy(dray_scene* scene);
+/* Same contract as dray_render but color/raw/count are device pointers on the scene's device
+ * and the work is enqueued on `stream` (a hipStream_t, NULL = default stream).  With stats == NULL
+ * the call returns once the work is enqueued; with stats it waits for completion and fills them. */
+int dray_render_device(const dray_camera* cam, dray_scene* scene, uint32_t* d_color, double* d_raw, int32_t* d_count,
+                       size_t buf_len, const dray_opts* opts, void* stream, dray_stats* stats);
+
+/* ---- scene recipes (host) ------------------------------------------------- */
+/* The scene built by the reference's local binary, main.rs:13-50, with its uniforms taken from the
+ * Philox stream (pixel = sample = stage = 0xFFFFFFFF) of `seed`.  Returns the sphere count or a
+ * negative dray_status (cap too small). */
+int dray_scene_final(uint64_t seed, dray_sphere* out, size_t cap);
+/* Ground + Lambertian + Dialectric + Metal test scene (4 spheres). */
+int dray_scene_three_spheres(dray_sphere* out, size_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
