@@ -51,9 +51,10 @@ def gather_image(slab, image_height, group=None):
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return slab[:image_height]
     G = dist.get_world_size(group)
-    gathered = torch.empty((G,) + tuple(slab.shape), dtype=slab.dtype, device=slab.device)
+    S, W = slab.shape
+    gathered = torch.empty((G * S, W), dtype=slab.dtype, device=slab.device)  # rank r's slab = rows r*S .. r*S+S-1
     dist.all_gather_into_tensor(gathered, slab.contiguous(), group=group)
-    return deinterleave(gathered, image_height, G)
+    return deinterleave(gathered.view(G, S, W), image_height, G)
 
 
 class DistributedRenderer:

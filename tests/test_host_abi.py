@@ -1,0 +1,141 @@
+"""CPU-side checks of the product library: it loads, exports every symbol include/dray.h declares, and its
+host logic (camera set-up, scene recipes, flattening, partition arithmetic, error reporting) agrees with the
+oracle.  No GPU compute is called here; GPU parity lives in the tests marked `gpu`."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import _oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol(dray):
+    from dray_amd import _ffi
+    header = open(os.path.join(ROOT, "include", "dray.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)   # declarations only, not the prose
+    declared = set(re.findall(r"\b(dray_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_ffi.EXPORTS), declared ^ set(_ffi.EXPORTS)
+    L = _ffi.lib()
+    for name in declared:
+        assert hasattr(L, name), name
+    assert dray.version().startswith("dray-hip")
+    assert L.dray_strerror(0) == b"ok" and b"buffer" in L.dray_strerror(-2) and b"unknown" in L.dray_strerror(-99)
+
+
+def test_struct_layouts_match_header(dray):
+    from dray_amd import _ffi
+    assert C.sizeof(_ffi.CameraPOD) == C.sizeof(O.Camera) == 8 + 16 + 8 + 72 + 16
+    assert C.sizeof(_ffi.SpherePOD) == C.sizeof(O.Sphere) == 72
+    assert C.sizeof(_ffi.Opts) == 40 and C.sizeof(_ffi.Stats) == 56
+    o = _ffi.default_opts()
+    assert (o.seed, o.mode, o.flags, o.sample_offset, o.device, o.row_begin, o.row_step) == (1, 1, 0, 0, -1, 0, 1)
+
+
+def cameras(dray):
+    yield dray.Camera.new()
+    yield dray.camera_final()
+    yield dray.camera_three_spheres()
+    c = dray.camera_final(width=333, spp=7, depth=3)
+    c.vfov, c.lookfrom, c.lookat, c.vup = 37.5, (1.5, -2.25, 7.0), (0.3, 0.1, -0.2), (0.1, 1.0, 0.2)
+    c.defocus_angle, c.focus_dist, c.aspect_ratio = 2.5, 3.4, 1.37
+    yield c
+
+
+def test_camera_initialize_matches_oracle_bit_for_bit(dray):
+    for cam in cameras(dray):
+        d = cam.initialize()
+        oc = O.default_camera()
+        oc.aspect_ratio, oc.image_width, oc.samples_per_pixel, oc.max_depth = cam.aspect_ratio, cam.image_width, cam.samples_per_pixel, cam.max_depth
+        oc.vfov, oc.lookfrom, oc.lookat, oc.vup = cam.vfov, O.v3(*cam.lookfrom), O.v3(*cam.lookat), O.v3(*cam.vup)
+        oc.defocus_angle, oc.focus_dist = cam.defocus_angle, cam.focus_dist
+        od = O.camera_initialize(oc)
+        assert d.image_height == od.image_height and d.pixel_samples_scale == od.pixel_samples_scale
+        for f in ("center", "pixel00_loc", "pixel_delta_u", "pixel_delta_v", "u", "v", "w", "defocus_disk_u", "defocus_disk_v"):
+            assert tuple(getattr(d, f)) == tuple(getattr(od, f)), f
+    cam = dray.Camera.new()                               # Camera::new defaults (camera.rs:147-163)
+    assert (cam.aspect_ratio, cam.image_width, cam.samples_per_pixel, cam.max_depth, cam.vfov) == (1.0, 100, 10, 10, 90.0)
+    assert cam.lookat == (0.0, 0.0, -1.0) and cam.vup == (0.0, 1.0, 0.0) and cam.focus_dist == 10.0
+    cam.initialize()
+    assert cam.image_height == 100
+    bad = dray.Camera.new()
+    bad.image_width = 0
+    with pytest.raises(dray.DrayError) as e:
+        bad.initialize()
+    assert e.value.status == -1
+
+
+def test_scene_recipes_match_oracle_and_fixture(dray):
+    for seed in (1, 2, 12345678901234567):
+        a, b = dray.scene_final(seed), O.scene_final(seed)
+        assert len(a) == len(b)
+        for f in ("center", "radius", "kind", "albedo", "fuzz_or_ior"):
+            assert (a[f] == b[f]).all(), f
+    a, b = dray.scene_three_spheres(), O.scene_three_spheres()
+    for f in ("center", "radius", "kind", "albedo", "fuzz_or_ior"):
+        assert (a[f] == b[f]).all()
+    txt = np.loadtxt(os.path.join(ROOT, "tests", "golden", "scene_final_seed1.txt"))
+    sp = dray.scene_final(1)
+    assert (txt[:, 0:3] == sp["center"]).all() and (txt[:, 5:8] == sp["albedo"]).all() and (txt[:, 8] == sp["fuzz_or_ior"]).all()
+    from dray_amd import _ffi
+    small = np.zeros(10, dtype=_ffi.SPHERE_DTYPE)
+    assert _ffi.lib().dray_scene_final(1, small.ctypes.data, len(small)) == _ffi.ERR_BUFFER_TOO_SMALL
+
+
+def test_world_flattening(dray):
+    w = dray.HittableList()
+    w.add(dray.Sphere((0, -1000, 0), 1000.0, dray.Lambertian((0.5, 0.5, 0.5))))
+    w.add(dray.Sphere((1, 2, 3), -4.0, dray.Metal((0.7, 0.6, 0.5), 3.0)))   # radius -> 0, fuzz -> 1
+    inner = dray.HittableList([dray.Sphere((0, 1, 0), 1.0, dray.Dialectric(1.5)), dray.Sphere((9, 9, 9), 2.0, dray.DefaultMaterial())])
+    w.add(inner)
+    flat = dray.flatten_world(w)
+    assert w.len() == 3 and len(flat) == 4
+    assert list(flat["kind"]) == [1, 2, 3, 0] and flat["radius"][1] == 0.0 and flat["fuzz_or_ior"][1] == 1.0
+    assert flat["fuzz_or_ior"][2] == 1.5 and tuple(flat["center"][3]) == (9.0, 9.0, 9.0)
+    assert w[0].radius() == 1000.0 and w[0].center() == (0.0, -1000.0, 0.0)
+
+    class BoundingBox(dray.Hittable):     # a hittable without a GPU form is refused, not skipped
+        pass
+
+    w.add(BoundingBox())
+    with pytest.raises(dray.DrayError) as e:
+        dray.flatten_world(w)
+    assert e.value.status == -3
+    w.clear()
+    assert len(dray.flatten_world(w)) == 0
+
+
+def test_no_gpu_means_loud_failure(dray):
+    """Without a device the render call reports an error; nothing falls back to a CPU path."""
+    if dray.device_count() > 0:
+        pytest.skip("a GPU is present")
+    cam = dray.camera_three_spheres(width=16, spp=1, depth=2)
+    buf = np.zeros(16 * 9, dtype=np.uint32)
+    with pytest.raises(dray.DrayError) as e:
+        cam.render(dray.scene_three_spheres(), None, buf, None, None)
+    assert e.value.status == -4
+    assert (buf == 0).all()
+
+
+def test_partition_arithmetic(dray):
+    from dray_amd import partition as P
+    for H in (1, 2, 7, 54, 675):
+        for G in (1, 2, 3, 4, 8):
+            rows = []
+            for r in range(G):
+                b, s, n = P.row_partition(H, G, r)
+                mine = list(range(b, H, s))
+                assert len(mine) == n <= P.slab_rows(H, G)
+                rows += mine
+            assert sorted(rows) == list(range(H))
+            slabs = np.full((G, P.slab_rows(H, G), 5), -1, dtype=np.int32)
+            for r in range(G):
+                for k, j in enumerate(range(r, H, G)):
+                    slabs[r, k, :] = j
+            img = P.deinterleave(slabs, H, G)
+            assert img.shape == (H, 5) and (img == np.arange(H)[:, None]).all()
+    with pytest.raises(ValueError):
+        P.row_partition(10, 2, 2)
