@@ -56,6 +56,7 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--mode", default="f32", choices=["f32", "f64", "f32plain"])
     ap.add_argument("--samples-per-item", type=int, default=0)
+    ap.add_argument("--variant", type=int, default=0, help="f32 scan formulation (A/B builds); 0 = library default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -81,7 +82,7 @@ def main():
     cam.seed = args.seed
     scene = ddev.DeviceScene(spheres, local_rank)
     renderer = partition.DistributedRenderer(
-        cam, partition.gpu_render_rows(scene, samples_per_item=args.samples_per_item),
+        cam, partition.gpu_render_rows(scene, samples_per_item=args.samples_per_item, variant=args.variant),
         partition.gpu_alloc(local_rank), rank=rank, world_size=world)
 
     def sync():
@@ -137,7 +138,7 @@ def main():
                                    "of the packed image per step" % (n_spheres, args.seed, args.width,
                                                                     cam.image_height, args.spp, args.depth, world),
                        "spheres": n_spheres, "width": args.width, "height": cam.image_height, "spp": args.spp,
-                       "max_depth": args.depth, "mode": args.mode, "partition": "rows j %% %d" % world},
+                       "max_depth": args.depth, "mode": args.mode, "variant": args.variant, "partition": "rows j %% %d" % world},
             "samples_per_s": total_samples / elapsed,
             "segments_per_sample": total_segs / max(total_samples, 1.0),
             "roofline": {

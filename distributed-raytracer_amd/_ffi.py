@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG_DIR, "libdray_hip.so")
+# DRAY_HIP_LIB selects another build of the same library (A/B timing of two builds on one GPU).
+LIB_PATH = os.environ.get("DRAY_HIP_LIB") or os.path.join(PKG_DIR, "libdray_hip.so")
 
 D3 = C.c_double * 3
 
@@ -91,7 +92,7 @@ class Opts(C.Structure):
         ("row_begin", C.c_int32),
         ("row_step", C.c_int32),
         ("samples_per_item", C.c_int32),
-        ("_reserved", C.c_int32),
+        ("variant", C.c_int32),
     ]
 
 
@@ -135,6 +136,12 @@ def lib():
         raise ImportError(
             "%s is missing: build it with __graft_entry__.build() or `make -C %s`; there is no CPU fallback"
             % (LIB_PATH, os.path.join(PKG_DIR, "csrc")))
+    try:
+        # torch ships its own libamdhip64; load it first so that this process has ONE HIP runtime and the
+        # streams and device pointers torch hands over belong to the runtime the library calls into
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     P = C.POINTER
     L.dray_version.restype = C.c_char_p

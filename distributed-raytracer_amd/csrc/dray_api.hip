@@ -139,7 +139,7 @@ void scene_free(dray_scene* s) {
     SceneDev& d = s->dev;
     (void)hipFree(d.geom64); (void)hipFree(d.mat64); (void)hipFree(d.kind);
     (void)hipFree(d.geom32); (void)hipFree(d.mat32);
-    (void)hipFree(d.narrow_geom); (void)hipFree(d.narrow_index); (void)hipFree(d.wide_index);
+    (void)hipFree(d.narrow_geom); (void)hipFree(d.narrow_pairs); (void)hipFree(d.narrow_index); (void)hipFree(d.wide_index);
     (void)hipFree(s->d_counters); (void)hipFree(s->d_accum);
     for (auto& e : s->ev)
         if (e) (void)hipEventDestroy(e);
@@ -206,10 +206,16 @@ int scene_create_impl(const dray_sphere* sp, size_t n, int32_t device, dray_scen
         ng.push_back(0.f); ng.push_back(0.f); ng.push_back(0.f); ng.push_back(-1e30f);
     }
     d.n_narrow_padded = (int32_t)nidx.size();
+    std::vector<float> np(ng.size());
+    for (size_t p = 0; p + 1 < nidx.size(); p += 2)
+        for (int q = 0; q < 4; ++q) {
+            np[4 * p + 2 * q + 0] = ng[4 * p + q];
+            np[4 * p + 2 * q + 1] = ng[4 * (p + 1) + q];
+        }
 
     int rc = DRAY_OK;
     if ((rc = upload(&d.geom64, g64)) || (rc = upload(&d.mat64, m64)) || (rc = upload(&d.kind, kind)) ||
-        (rc = upload(&d.geom32, g32)) || (rc = upload(&d.mat32, m32)) || (rc = upload(&d.narrow_geom, ng)) ||
+        (rc = upload(&d.geom32, g32)) || (rc = upload(&d.mat32, m32)) || (rc = upload(&d.narrow_geom, ng)) || (rc = upload(&d.narrow_pairs, np)) ||
         (rc = upload(&d.narrow_index, nidx)) || (rc = upload(&d.wide_index, widx))) {
         scene_free(s);
         return rc;
@@ -268,7 +274,7 @@ int render_device_impl(const dray_camera* cam, dray_scene* scene, uint32_t* d_co
     HIP_TRY(hipMemsetAsync(scene->d_counters, 0, sizeof(DeviceCounters), stream));
     if (opts.mode == DRAY_MODE_F32) {
         const CamDev<float> c = make_cam<float>(*cam, dv);
-        const F32Plan plan = plan_render_f32(c, part, opts.samples_per_item, scene->device);
+        const F32Plan plan = plan_render_f32(c, part, opts.samples_per_item, opts.variant, scene->device);
         if (plan.accum_words > scene->accum_capacity) {
             if (scene->d_accum) HIP_TRY(hipFree(scene->d_accum));
             scene->d_accum = nullptr;

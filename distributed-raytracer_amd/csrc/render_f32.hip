@@ -94,8 +94,90 @@ __device__ __forceinline__ uint32_t to_fixed(float c) {
     return (uint32_t)(fminf(fmaxf(c, 0.f), kFixMax) * kFixScale);
 }
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+struct ScanBest {
+    float t;      // closest accepted root so far (INFINITY: none)
+    int32_t pos;  // its position in the narrow table, -1: none
+    bool far;     // the far root was the accepted one
+};
+
+__device__ __forceinline__ void scan_accept(ScanBest& b, float h, float disc, float tmin, int32_t pos) { // sphere.rs:40-48
+    const float sq = fsqrt(disc);
+    const float t0 = h - sq;
+    const bool far = !(t0 > tmin);
+    const float t = far ? h + sq : t0;
+    if (t > tmin && t < b.t) {
+        b.t = t;
+        b.pos = pos;
+        b.far = far;
+    }
+}
+
+// The scan visits the narrow spheres in insertion order and calls on_candidate(h, disc, position) for every
+// sphere whose line-sphere discriminant is non-negative (sphere.rs:29-36 with |d| = 1:
+// disc = h^2 - (|oc|^2 - r^2)).  The table address is the same for all lanes, so the geometry arrives through
+// scalar loads (two s_load_dwordx16 per 8 spheres) and feeds the VALU as scalar operands.
+
+// One sphere per VALU instruction.
+template <typename OnCandidate>
+__device__ __forceinline__ void scan_plain(const float4* __restrict__ narrow_geom, int32_t n_padded, const PathRay& ray,
+                                           OnCandidate&& on_candidate) {
+    const float ox = ray.o.x, oy = ray.o.y, oz = ray.o.z, dx = ray.d.x, dy = ray.d.y, dz = ray.d.z;
+    for (int32_t k = 0; k < n_padded; k += kUnroll) {
+        float hv[kUnroll], dv[kUnroll];
+#pragma unroll
+        for (int32_t u = 0; u < kUnroll; ++u) {
+            const float4 s = narrow_geom[k + u];
+            const float ocx = s.x - ox, ocy = s.y - oy, ocz = s.z - oz;
+            hv[u] = fmaf(ocz, dz, fmaf(ocy, dy, ocx * dx));
+            const float q = fmaf(-ocz, ocz, fmaf(-ocy, ocy, fmaf(-ocx, ocx, s.w)));
+            dv[u] = fmaf(hv[u], hv[u], q);
+        }
+#pragma unroll
+        for (int32_t u = 0; u < kUnroll; ++u)
+            if (dv[u] >= 0.f) on_candidate(hv[u], dv[u], k + u);
+    }
+}
+
+// Two spheres per packed-f32 instruction.  The pair table holds, per two consecutive spheres,
+// (cx0,cx1),(cy0,cy1),(cz0,cz1),(r0^2,r1^2); the ray's components are splat into both halves.
+template <typename OnCandidate>
+__device__ __forceinline__ void scan_packed(const v2f* __restrict__ pairs, int32_t n_padded, const PathRay& ray,
+                                            OnCandidate&& on_candidate) {
+    const v2f ox = {ray.o.x, ray.o.x}, oy = {ray.o.y, ray.o.y}, oz = {ray.o.z, ray.o.z};
+    const v2f dx = {ray.d.x, ray.d.x}, dy = {ray.d.y, ray.d.y}, dz = {ray.d.z, ray.d.z};
+    constexpr int kPairs = kUnroll / 2;
+    for (int32_t k = 0; k < n_padded; k += kUnroll) {
+        v2f hv[kPairs], dv[kPairs];
+#pragma unroll
+        for (int32_t u = 0; u < kPairs; ++u) {
+            const v2f* g = pairs + (size_t)(k / 2 + u) * 4;
+            const v2f ocx = g[0] - ox, ocy = g[1] - oy, ocz = g[2] - oz;
+            v2f h = ocx * dx;
+            h = __builtin_elementwise_fma(ocy, dy, h);
+            h = __builtin_elementwise_fma(ocz, dz, h);
+            v2f q = __builtin_elementwise_fma(-ocx, ocx, g[3]);
+            q = __builtin_elementwise_fma(-ocy, ocy, q);
+            q = __builtin_elementwise_fma(-ocz, ocz, q);
+            hv[u] = h;
+            dv[u] = __builtin_elementwise_fma(h, h, q);
+        }
+#pragma unroll
+        for (int32_t u = 0; u < kPairs; ++u) {
+            if (dv[u].x >= 0.f) on_candidate(hv[u].x, dv[u].x, k + 2 * u);
+            if (dv[u].y >= 0.f) on_candidate(hv[u].y, dv[u].y, k + 2 * u + 1);
+        }
+    }
+}
+
+constexpr int kPoolItems = 64; // work items a wave takes from the global queue per atomic
+constexpr int kQueueCap = 16; // per-lane candidate slots in LDS (variants 2, 3)
+
+template <int VARIANT>
 __global__ __launch_bounds__(256) void render_f32_kernel(
-    CamDev<float> cam, const float4* __restrict__ narrow_geom, const int32_t* __restrict__ narrow_index,
+    CamDev<float> cam, const float4* __restrict__ narrow_geom, const v2f* __restrict__ narrow_pairs,
+    const int32_t* __restrict__ narrow_index,
     int32_t n_narrow_padded, const int32_t* __restrict__ wide_index, int32_t n_wide,
     const double* __restrict__ geom64, const float4* __restrict__ geom32, const float4* __restrict__ mat32,
     const uint32_t* __restrict__ kind, Partition part, RngKey key, int32_t samples_per_item, int32_t n_chunks,
@@ -109,6 +191,8 @@ __global__ __launch_bounds__(256) void render_f32_kernel(
     int32_t pi = 0, pj = 0;
     unsigned long long acc_r = 0, acc_g = 0, acc_b = 0;
     uint32_t n_seg = 0, n_samples = 0;
+
+    unsigned long long pool_next = 0ull, pool_end = 0ull; // wave-uniform
 
     PathRay ray = {{0.f, 0.f, 0.f}, {0.f, 0.f, 1.f}, 0.001f};
     F3 thr = {1.f, 1.f, 1.f};
@@ -124,14 +208,25 @@ __global__ __launch_bounds__(256) void render_f32_kernel(
             atomicAdd(&accum[2 * npix + pix], acc_b);
             have_item = false;
         }
-        const unsigned long long want = __ballot(need_item);
-        if (want != 0ull) {
-            const int leader = __ffsll((long long)want) - 1;
-            unsigned long long base = 0ull;
-            if (lane == leader) base = atomicAdd(&counters->next_item, (unsigned long long)__popcll(want));
-            base = __shfl(base, leader, 64);
-            if (need_item) {
-                const unsigned long long item = base + (unsigned long long)__popcll(want & ((1ull << lane) - 1ull));
+        // Work items come from a wave-private pool [pool_next, pool_end) that one returning atomic on the
+        // global queue head refills kPoolItems at a time, so a lane's refill usually costs no memory round trip.
+        unsigned long long want = __ballot(need_item);
+        while (want != 0ull) {
+            if (pool_next == pool_end) { // wave-uniform
+                unsigned long long base = 0ull;
+                if (lane == 0) base = atomicAdd(&counters->next_item, (unsigned long long)kPoolItems);
+                const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)base, 0);
+                const uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(base >> 32), 0);
+                pool_next = ((unsigned long long)hi << 32) | lo; // scalar registers
+                pool_end = pool_next + (unsigned long long)kPoolItems;
+            }
+            const unsigned long long avail = pool_end - pool_next;
+            const int wanted = __popcll(want);
+            const int take = (unsigned long long)wanted < avail ? wanted : (int)avail;
+            const int rank = __popcll(want & ((1ull << lane) - 1ull));
+            if (need_item && rank < take) {
+                const unsigned long long item = pool_next + (unsigned long long)rank;
+                need_item = false;
                 if (item >= n_items) {
                     done = true;
                 } else {
@@ -147,6 +242,8 @@ __global__ __launch_bounds__(256) void render_f32_kernel(
                     st.pixel = (uint32_t)pj * (uint32_t)cam.W + (uint32_t)pi;
                 }
             }
+            pool_next += (unsigned long long)take;
+            want = __ballot(need_item);
         }
         if (!alive && !done) { // next sample of the item: camera.rs:224
             st.sample = key.sample_offset + (uint32_t)s_next;
@@ -165,38 +262,47 @@ __global__ __launch_bounds__(256) void render_f32_kernel(
             n_seg++;
             const float ox = ray.o.x, oy = ray.o.y, oz = ray.o.z, dx = ray.d.x, dy = ray.d.y, dz = ray.d.z;
             const float tmin = ray.tmin;
-            float best = INFINITY;
-            int32_t bpos = -1; // position in the narrow table
-            bool bfar = false;
-            for (int32_t k = 0; k < n_narrow_padded; k += kUnroll) {
-                // Phase 1, no branches: discriminants of kUnroll spheres (sphere.rs:29-34 with |d| = 1,
-                // disc = h^2 - (|oc|^2 - r^2)).  The addresses are the same for all lanes, so the
-                // geometry arrives through scalar loads and feeds the VALU as scalar operands.
-                float hv[kUnroll], dv[kUnroll];
-#pragma unroll
-                for (int32_t u = 0; u < kUnroll; ++u) {
-                    const float4 s = narrow_geom[k + u];
-                    const float ocx = s.x - ox, ocy = s.y - oy, ocz = s.z - oz;
-                    hv[u] = fmaf(ocz, dz, fmaf(ocy, dy, ocx * dx));
-                    const float q = fmaf(-ocz, ocz, fmaf(-ocy, ocy, fmaf(-ocx, ocx, s.w)));
-                    dv[u] = fmaf(hv[u], hv[u], q);
-                }
-                // Phase 2: roots only where the line meets the sphere (sphere.rs:36-48).
-#pragma unroll
-                for (int32_t u = 0; u < kUnroll; ++u) {
-                    if (dv[u] >= 0.f) {
-                        const float sq = fsqrt(dv[u]);
-                        const float t0 = hv[u] - sq;
-                        const bool far = !(t0 > tmin);
-                        const float t = far ? hv[u] + sq : t0;
-                        if (t > tmin && t < best) {
-                            best = t;
-                            bpos = k + u;
-                            bfar = far;
-                        }
+            ScanBest sb = {INFINITY, -1, false};
+            if constexpr (VARIANT == 0 || VARIANT == 1) {
+                // roots evaluated where the candidate is found
+                auto accept = [&](float h, float disc, int32_t pos) { scan_accept(sb, h, disc, tmin, pos); };
+                if constexpr (VARIANT == 1)
+                    scan_packed(narrow_pairs, n_narrow_padded, ray, accept);
+                else
+                    scan_plain(narrow_geom, n_narrow_padded, ray, accept);
+            } else {
+                // candidates are only recorded during the scan (one LDS store each) and their roots are
+                // evaluated afterwards, each lane walking its own short list; slot s of a lane is word
+                // s*256 + tid, which is conflict-free for any mix of per-lane fill levels
+                __shared__ uint32_t queue[kQueueCap * 256];
+                uint32_t* const my_queue = queue + threadIdx.x;
+                int32_t n_queued = 0;
+                auto push = [&](float h, float disc, int32_t pos) {
+                    if (n_queued < kQueueCap) {
+                        my_queue[n_queued * 256] = (uint32_t)pos;
+                        n_queued++;
+                    } else {
+                        scan_accept(sb, h, disc, tmin, pos); // list full: evaluate in place
+                    }
+                };
+                if constexpr (VARIANT == 3)
+                    scan_packed(narrow_pairs, n_narrow_padded, ray, push);
+                else
+                    scan_plain(narrow_geom, n_narrow_padded, ray, push);
+                for (int32_t q = 0; __ballot(q < n_queued) != 0ull; ++q) {
+                    if (q < n_queued) {
+                        const int32_t pos = (int32_t)my_queue[q * 256];
+                        const float4 s = narrow_geom[pos];
+                        const float ocx = s.x - ox, ocy = s.y - oy, ocz = s.z - oz;
+                        const float h = fmaf(ocz, dz, fmaf(ocy, dy, ocx * dx));
+                        const float qq = fmaf(-ocz, ocz, fmaf(-ocy, ocy, fmaf(-ocx, ocx, s.w)));
+                        scan_accept(sb, h, fmaf(h, h, qq), tmin, pos);
                     }
                 }
             }
+            float best = sb.t;
+            const int32_t bpos = sb.pos;
+            const bool bfar = sb.far;
             // Re-evaluate the winner from the perpendicular remainder |oc - h d|, which does not cancel.
             int32_t bidx = -1; // position in the caller's list
             F3 hp = {0.f, 0.f, 0.f}, hn = {0.f, 0.f, 0.f};
@@ -213,27 +319,34 @@ __global__ __launch_bounds__(256) void render_f32_kernel(
                 const float ir = rcp(s.w);
                 hn = {(hp.x - s.x) * ir, (hp.y - s.y) * ir, (hp.z - s.z) * ir}; // sphere.rs:52
             }
-            for (int32_t wq = 0; wq < n_wide; ++wq) { // sphere.rs:28-57 in f64
+            for (int32_t wq = 0; wq < n_wide; ++wq) {
+                // sphere.rs:28-57 in f64 for a sphere too large for f32: the cancelling terms (oc, |oc|^2 - r^2,
+                // the discriminant, the hit point relative to the centre) are f64; divisions are avoided
+                // (1/|d|^2 = 2 - |d|^2 to 1e-14 because d is unit to f32 rounding; sqrt = f32 estimate + one Newton step)
                 const int32_t idx = wide_index[wq];
                 const double cx = geom64[4 * idx + 0], cy = geom64[4 * idx + 1], cz = geom64[4 * idx + 2];
                 const double rad = geom64[4 * idx + 3];
                 const double ocx = cx - (double)ox, ocy = cy - (double)oy, ocz = cz - (double)oz;
                 const double ddx = dx, ddy = dy, ddz = dz;
-                const double a = ddx * ddx + ddy * ddy + ddz * ddz;
-                const double h = ddx * ocx + ddy * ocy + ddz * ocz;
-                const double c = ocx * ocx + ocy * ocy + ocz * ocz - rad * rad;
-                const double disc = h * h - a * c;
+                const double a = fma(ddz, ddz, fma(ddy, ddy, ddx * ddx));
+                const double h = fma(ddz, ocz, fma(ddy, ocy, ddx * ocx));
+                const double c = fma(ocz, ocz, fma(ocy, ocy, fma(ocx, ocx, -(rad * rad))));
+                const double disc = fma(h, h, -(a * c));
                 if (disc >= 0.) {
-                    const double sq = sqrt(disc);
-                    double t = (h - sq) / a;
-                    if (!(t > (double)tmin)) t = (h + sq) / a;
+                    const float s0f = fsqrt((float)disc);
+                    const double s0 = (double)s0f;
+                    const double sq = s0f > 0.f ? fma(fma(-s0, s0, disc), (double)(0.5f * rcp(s0f)), s0) : 0.;
+                    const double inva = 2.0 - a;
+                    double t = (h - sq) * inva;
+                    if (!(t > (double)tmin)) t = (h + sq) * inva;
                     const float tf = (float)t;
                     if (t > (double)tmin && (tf < best || (tf == best && idx < bidx))) {
                         best = tf;
                         bidx = idx;
-                        const double px = (double)ox + t * ddx, py = (double)oy + t * ddy, pz = (double)oz + t * ddz;
+                        const double px = fma(t, ddx, (double)ox), py = fma(t, ddy, (double)oy), pz = fma(t, ddz, (double)oz);
                         hp = {(float)px, (float)py, (float)pz};
-                        hn = {(float)((px - cx) / rad), (float)((py - cy) / rad), (float)((pz - cz) / rad)};
+                        const float ir = rcp((float)rad);
+                        hn = {(float)(px - cx) * ir, (float)(py - cy) * ir, (float)(pz - cz) * ir}; // sphere.rs:52
                     }
                 }
             }
@@ -342,14 +455,16 @@ __global__ __launch_bounds__(256) void resolve_f32_kernel(int32_t W, int32_t spp
 
 } // namespace
 
-F32Plan plan_render_f32(const CamDev<float>& cam, const Partition& part, int32_t samples_per_item, int device) {
+F32Plan plan_render_f32(const CamDev<float>& cam, const Partition& part, int32_t samples_per_item, int32_t variant,
+                        int device) {
     F32Plan plan{};
+    plan.variant = variant;
     plan.block = 256;
     int cus = 256, per_cu = 4;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
     int occ = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, render_f32_kernel, plan.block, 0) == hipSuccess && occ > 0)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, render_f32_kernel<0>, plan.block, 0) == hipSuccess && occ > 0)
         per_cu = occ;
     plan.grid = cus * per_cu;
     const long long npix = (long long)part.n_rows * cam.W;
@@ -374,8 +489,12 @@ hipError_t launch_render_f32(const CamDev<float>& cam, const SceneDev& scene, co
     const long long npix = (long long)part.n_rows * cam.W;
     if (npix <= 0 || cam.spp <= 0) return hipSuccess;
     const unsigned long long n_items = (unsigned long long)npix * (unsigned long long)plan.n_chunks;
-    hipLaunchKernelGGL(render_f32_kernel, dim3(plan.grid), dim3(plan.block), 0, stream, cam,
-                       (const float4*)scene.narrow_geom, scene.narrow_index, scene.n_narrow_padded, scene.wide_index,
+    auto kern = render_f32_kernel<0>;
+    if (plan.variant == 1) kern = render_f32_kernel<1>;
+    if (plan.variant == 2) kern = render_f32_kernel<2>;
+    if (plan.variant == 3) kern = render_f32_kernel<3>;
+    hipLaunchKernelGGL(kern, dim3(plan.grid), dim3(plan.block), 0, stream, cam, (const float4*)scene.narrow_geom,
+                       (const v2f*)scene.narrow_pairs, scene.narrow_index, scene.n_narrow_padded, scene.wide_index,
                        scene.n_wide, scene.geom64, (const float4*)scene.geom32, (const float4*)scene.mat32, scene.kind,
                        part, key, plan.samples_per_item, plan.n_chunks, n_items, d_accum, d_counters);
     return hipGetLastError();

@@ -112,7 +112,7 @@ typedef struct dray_opts {
     int32_t row_begin;        /* scanline partition: rows row_begin, row_begin+row_step, ... */
     int32_t row_step;         /* 0 is read as 1 */
     int32_t samples_per_item; /* f32 mode: samples per work item, 0 = library default */
-    int32_t _reserved;
+    int32_t variant;          /* f32 mode: scan formulation, 0 = library default; others are A/B builds */
 } dray_opts;
 
 typedef struct dray_stats {

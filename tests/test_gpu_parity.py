@@ -171,6 +171,18 @@ def test_f32_item_size_invariance(dray, gpu):
     assert (cnt == 10).all()
 
 
+def test_f32_scan_variants_agree(dray, gpu):
+    """The packed-f32 scan performs the same operations on the same operands as the one-sphere-per-instruction
+    scan, two spheres at a time: images, sums and segment counts are identical."""
+    spheres = dray.scene_final(1)
+    cam = dray.camera_final(width=96, spp=12, depth=50)
+    cam.mode = dray.MODE_F32
+    a = render_gpu(dray, gpu, spheres, cam, seed=13, variant=0)
+    for v in (1, 2, 3):
+        b = render_gpu(dray, gpu, spheres, cam, seed=13, variant=v)
+        assert (a[0] == b[0]).all() and (a[1] == b[1]).all() and a[3].segments == b[3].segments, v
+
+
 def test_f32_close_to_oracle(dray, gpu, oracle):
     """f32 throughput kernel vs the f64 oracle on identical Philox streams.
 
