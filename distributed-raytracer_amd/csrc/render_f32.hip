@@ -119,8 +119,9 @@ __device__ __forceinline__ void scan_accept(ScanBest& b, float h, float disc, fl
 // disc = h^2 - (|oc|^2 - r^2)).  The table address is the same for all lanes, so the geometry arrives through
 // scalar loads (two s_load_dwordx16 per 8 spheres) and feeds the VALU as scalar operands.
 
-// One sphere per VALU instruction.
-template <typename OnCandidate>
+// One sphere per VALU instruction.  BLOCK_TEST: one max over the 8 discriminants decides whether any lane has a
+// candidate in the block at all (candidates are rare), replacing 8 compare-and-branch sequences by one.
+template <bool BLOCK_TEST, typename OnCandidate>
 __device__ __forceinline__ void scan_plain(const float4* __restrict__ narrow_geom, int32_t n_padded, const PathRay& ray,
                                            OnCandidate&& on_candidate) {
     const float ox = ray.o.x, oy = ray.o.y, oz = ray.o.z, dx = ray.d.x, dy = ray.d.y, dz = ray.d.z;
@@ -133,6 +134,12 @@ __device__ __forceinline__ void scan_plain(const float4* __restrict__ narrow_geo
             hv[u] = fmaf(ocz, dz, fmaf(ocy, dy, ocx * dx));
             const float q = fmaf(-ocz, ocz, fmaf(-ocy, ocy, fmaf(-ocx, ocx, s.w)));
             dv[u] = fmaf(hv[u], hv[u], q);
+        }
+        if constexpr (BLOCK_TEST) {
+            float m = dv[0];
+#pragma unroll
+            for (int32_t u = 1; u < kUnroll; ++u) m = fmaxf(m, dv[u]);
+            if (!(m >= 0.f)) continue;
         }
 #pragma unroll
         for (int32_t u = 0; u < kUnroll; ++u)
@@ -263,13 +270,13 @@ __global__ __launch_bounds__(256) void render_f32_kernel(
             const float ox = ray.o.x, oy = ray.o.y, oz = ray.o.z, dx = ray.d.x, dy = ray.d.y, dz = ray.d.z;
             const float tmin = ray.tmin;
             ScanBest sb = {INFINITY, -1, false};
-            if constexpr (VARIANT == 0 || VARIANT == 1) {
+            if constexpr (VARIANT == 0 || VARIANT == 1 || VARIANT == 4) {
                 // roots evaluated where the candidate is found
                 auto accept = [&](float h, float disc, int32_t pos) { scan_accept(sb, h, disc, tmin, pos); };
                 if constexpr (VARIANT == 1)
                     scan_packed(narrow_pairs, n_narrow_padded, ray, accept);
                 else
-                    scan_plain(narrow_geom, n_narrow_padded, ray, accept);
+                    scan_plain<VARIANT == 4>(narrow_geom, n_narrow_padded, ray, accept);
             } else {
                 // candidates are only recorded during the scan (one LDS store each) and their roots are
                 // evaluated afterwards, each lane walking its own short list; slot s of a lane is word
@@ -288,7 +295,7 @@ __global__ __launch_bounds__(256) void render_f32_kernel(
                 if constexpr (VARIANT == 3)
                     scan_packed(narrow_pairs, n_narrow_padded, ray, push);
                 else
-                    scan_plain(narrow_geom, n_narrow_padded, ray, push);
+                    scan_plain<false>(narrow_geom, n_narrow_padded, ray, push);
                 for (int32_t q = 0; __ballot(q < n_queued) != 0ull; ++q) {
                     if (q < n_queued) {
                         const int32_t pos = (int32_t)my_queue[q * 256];
@@ -470,9 +477,12 @@ F32Plan plan_render_f32(const CamDev<float>& cam, const Partition& part, int32_t
     const long long npix = (long long)part.n_rows * cam.W;
     const long long lanes = (long long)plan.grid * plan.block;
     int32_t s = samples_per_item;
-    if (s <= 0) { // aim at ~48 items per lane so that the last items of the launch cost little
-        long long want = ((long long)cam.spp * npix) / (lanes * 48 > 0 ? lanes * 48 : 1);
-        s = (int32_t)(want < 1 ? 1 : (want > 32 ? 32 : want));
+    if (s <= 0) {
+        // Measured on the 485-sphere frame: 2..8 samples per item are fastest (short items keep a wave's lanes on
+        // neighbouring pixels and the launch's tail short; 1 sample per item makes every lane's flush contend
+        // on the same three words).  Aim at ~192 items per lane within that range.
+        long long want = ((long long)cam.spp * npix) / (lanes * 192 > 0 ? lanes * 192 : 1);
+        s = (int32_t)(want < 2 ? 2 : (want > 8 ? 8 : want));
     }
     if (s > cam.spp) s = cam.spp > 0 ? cam.spp : 1;
     plan.samples_per_item = s;
@@ -493,6 +503,7 @@ hipError_t launch_render_f32(const CamDev<float>& cam, const SceneDev& scene, co
     if (plan.variant == 1) kern = render_f32_kernel<1>;
     if (plan.variant == 2) kern = render_f32_kernel<2>;
     if (plan.variant == 3) kern = render_f32_kernel<3>;
+    if (plan.variant == 4) kern = render_f32_kernel<4>;
     hipLaunchKernelGGL(kern, dim3(plan.grid), dim3(plan.block), 0, stream, cam, (const float4*)scene.narrow_geom,
                        (const v2f*)scene.narrow_pairs, scene.narrow_index, scene.n_narrow_padded, scene.wide_index,
                        scene.n_wide, scene.geom64, (const float4*)scene.geom32, (const float4*)scene.mat32, scene.kind,
