@@ -139,7 +139,7 @@ void scene_free(dray_scene* s) {
     SceneDev& d = s->dev;
     (void)hipFree(d.geom64); (void)hipFree(d.mat64); (void)hipFree(d.kind);
     (void)hipFree(d.geom32); (void)hipFree(d.mat32);
-    (void)hipFree(d.narrow_geom); (void)hipFree(d.narrow_pairs); (void)hipFree(d.narrow_index); (void)hipFree(d.wide_index);
+    (void)hipFree(d.narrow_geom); (void)hipFree(d.narrow_pairs); (void)hipFree(d.narrow_tiles); (void)hipFree(d.filter_geom); (void)hipFree(d.filter_zw); (void)hipFree(d.narrow_index); (void)hipFree(d.wide_index);
     (void)hipFree(s->d_counters); (void)hipFree(s->d_accum);
     for (auto& e : s->ev)
         if (e) (void)hipEventDestroy(e);
@@ -213,9 +213,33 @@ int scene_create_impl(const dray_sphere* sp, size_t n, int32_t device, dray_scen
             np[4 * p + 2 * q + 1] = ng[4 * (p + 1) + q];
         }
 
+    // tiles for the matrix-core filter; unused slots hold a sphere no ray can list (w = -1e30)
+    d.n_tiles = (int32_t)((d.n_narrow + 15) / 16);
+    std::vector<float> tiles((size_t)(d.n_tiles + 1) * 64, 0.f);
+    for (size_t t = 0; t < (size_t)d.n_tiles + 1; ++t)
+        for (int q = 0; q < 16; ++q) tiles[t * 64 + 48 + q] = -1e30f;
+    std::vector<float> fg(ng.size(), 0.f); // the scan table with w in place of r^2; padding entries are never listed
+    for (size_t p = (size_t)d.n_narrow; p < nidx.size(); ++p) fg[4 * p + 3] = -1e30f;
+    for (int32_t p = 0; p < d.n_narrow; ++p) {
+        const float cx = ng[4 * p + 0], cy = ng[4 * p + 1], cz = ng[4 * p + 2], r2 = ng[4 * p + 3];
+        const double c2 = (double)cx * cx + (double)cy * cy + (double)cz * cz;
+        const double w = (double)r2 - c2 + 7.62939453125e-6 * (c2 + (double)r2); // slack 2^-17 (|c|^2 + r^2)
+        float wf = (float)w;
+        if ((double)wf < w) wf = std::nextafterf(wf, INFINITY); // round towards listing
+        fg[4 * p + 0] = cx; fg[4 * p + 1] = cy; fg[4 * p + 2] = cz; fg[4 * p + 3] = wf;
+        float* tile = &tiles[(size_t)(p / 16) * 64];
+        tile[p % 16] = cx; tile[16 + p % 16] = cy; tile[32 + p % 16] = cz; tile[48 + p % 16] = wf;
+    }
+
+    std::vector<float> fzw(fg.size() / 2);
+    for (size_t p = 0; p < nidx.size(); ++p) {
+        fzw[2 * p + 0] = fg[4 * p + 2];
+        fzw[2 * p + 1] = fg[4 * p + 3];
+    }
+
     int rc = DRAY_OK;
     if ((rc = upload(&d.geom64, g64)) || (rc = upload(&d.mat64, m64)) || (rc = upload(&d.kind, kind)) ||
-        (rc = upload(&d.geom32, g32)) || (rc = upload(&d.mat32, m32)) || (rc = upload(&d.narrow_geom, ng)) || (rc = upload(&d.narrow_pairs, np)) ||
+        (rc = upload(&d.geom32, g32)) || (rc = upload(&d.mat32, m32)) || (rc = upload(&d.narrow_geom, ng)) || (rc = upload(&d.narrow_pairs, np)) || (rc = upload(&d.narrow_tiles, tiles)) || (rc = upload(&d.filter_geom, fg)) || (rc = upload(&d.filter_zw, fzw)) ||
         (rc = upload(&d.narrow_index, nidx)) || (rc = upload(&d.wide_index, widx))) {
         scene_free(s);
         return rc;
@@ -274,7 +298,7 @@ int render_device_impl(const dray_camera* cam, dray_scene* scene, uint32_t* d_co
     HIP_TRY(hipMemsetAsync(scene->d_counters, 0, sizeof(DeviceCounters), stream));
     if (opts.mode == DRAY_MODE_F32) {
         const CamDev<float> c = make_cam<float>(*cam, dv);
-        const F32Plan plan = plan_render_f32(c, part, opts.samples_per_item, opts.variant, scene->device);
+        const F32Plan plan = plan_render_f32(c, part, opts.samples_per_item, opts.variant, scene->dev.n_narrow_padded, scene->device);
         if (plan.accum_words > scene->accum_capacity) {
             if (scene->d_accum) HIP_TRY(hipFree(scene->d_accum));
             scene->d_accum = nullptr;

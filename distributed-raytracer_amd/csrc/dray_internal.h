@@ -43,8 +43,14 @@ struct SceneDev {
     // throughput kernel: "narrow" spheres are scanned in f32, "wide" ones (large radius) in f64
     int32_t n_narrow = 0, n_wide = 0;
     float* narrow_geom = nullptr;    // n_narrow_padded x 4: cx, cy, cz, r*r  (padding never hits)
+    float* filter_geom = nullptr;    // n_narrow_padded x 4: cx, cy, cz, w = r^2 - |c|^2 + slack (expanded-form filter)
+    float* filter_zw = nullptr;      // n_narrow_padded/2 x 4: cz0, w0, cz1, w1 of the filter table
     float* narrow_pairs = nullptr;   // the same table as pairs: (cx0,cx1),(cy0,cy1),(cz0,cz1),(r0^2,r1^2)
     int32_t* narrow_index = nullptr; // position in the caller's list
+    // matrix-core filter: tiles of 16 narrow spheres, 64 floats each: cx[16] cy[16] cz[16] w[16], w = r^2-|c|^2+slack,
+    // plus one spare tile at the end (the kernel prefetches one tile ahead)
+    float* narrow_tiles = nullptr;
+    int32_t n_tiles = 0;
     int32_t n_narrow_padded = 0;
     int32_t* wide_index = nullptr; // positions of the wide spheres, ascending
 };
@@ -70,10 +76,11 @@ struct F32Plan {
     int32_t n_chunks;         // ceil(spp / samples_per_item)
     size_t accum_words;       // 3 * n_rows * W fixed-point sums (u64), zeroed before the launch
     int32_t grid, block;
+    size_t lds_bytes; // dynamic LDS of the launch
     int32_t variant; // scan formulation: 0 one sphere per instruction, 1 two spheres per packed-f32 instruction
 };
 F32Plan plan_render_f32(const CamDev<float>& cam, const Partition& part, int32_t samples_per_item, int32_t variant,
-                        int device);
+                        int32_t n_narrow_padded, int device);
 hipError_t launch_render_f32(const CamDev<float>& cam, const SceneDev& scene, const Partition& part, const RngKey& key,
                              const F32Plan& plan, unsigned long long* d_accum, DeviceCounters* d_counters,
                              hipStream_t stream);

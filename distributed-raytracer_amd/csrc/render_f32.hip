@@ -102,12 +102,15 @@ struct ScanBest {
     bool far;     // the far root was the accepted one
 };
 
+// TIE: candidates may arrive out of insertion order, so on equal t the earlier sphere is kept explicitly
+// (hittable_list.rs:65-70); in an in-order scan the strict comparison alone does that.
+template <bool TIE = false>
 __device__ __forceinline__ void scan_accept(ScanBest& b, float h, float disc, float tmin, int32_t pos) { // sphere.rs:40-48
     const float sq = fsqrt(disc);
     const float t0 = h - sq;
     const bool far = !(t0 > tmin);
     const float t = far ? h + sq : t0;
-    if (t > tmin && t < b.t) {
+    if (t > tmin && (t < b.t || (TIE && t == b.t && pos < b.pos))) {
         b.t = t;
         b.pos = pos;
         b.far = far;
@@ -178,19 +181,121 @@ __device__ __forceinline__ void scan_packed(const v2f* __restrict__ pairs, int32
     }
 }
 
+// The scan of scan_plain with the geometry read from LDS instead of through scalar loads.  On gfx950 a VALU
+// operation with an SGPR (or DPP) operand issues at about 3.6 cycles per wave against 2.2 for VGPR-only operands
+// (tools/ubench_operand.hip), and 4 of the 11 operations per test take sphere data.  A wave-uniform ds_read_b128
+// broadcasts one sphere into 4 VGPRs without using the VALU, so all 11 operations become VGPR-only.
+template <typename OnCandidate>
+__device__ __forceinline__ void scan_lds(const float4* lds_geom, int32_t n_padded, const PathRay& ray,
+                                         OnCandidate&& on_candidate) {
+    const float ox = ray.o.x, oy = ray.o.y, oz = ray.o.z, dx = ray.d.x, dy = ray.d.y, dz = ray.d.z;
+    constexpr int kStep = 4;
+    for (int32_t k = 0; k < n_padded; k += kStep) {
+        float hv[kStep], dv[kStep];
+#pragma unroll
+        for (int32_t u = 0; u < kStep; ++u) {
+            const float4 s = lds_geom[k + u];
+            const float ocx = s.x - ox, ocy = s.y - oy, ocz = s.z - oz;
+            hv[u] = fmaf(ocz, dz, fmaf(ocy, dy, ocx * dx));
+            const float q = fmaf(-ocz, ocz, fmaf(-ocy, ocy, fmaf(-ocx, ocx, s.w)));
+            dv[u] = fmaf(hv[u], hv[u], q);
+        }
+#pragma unroll
+        for (int32_t u = 0; u < kStep; ++u)
+            if (dv[u] >= 0.f) on_candidate(hv[u], dv[u], k + u);
+    }
+}
+
+// Expanded-form filter, one sphere per VALU instruction, 9 operations per test instead of 11:
+//   h = d.c - d.o  (3 fma, first one starting from -d.o),   s = 2 o.c - |o|^2 (3 fma, first one starting from -|o|^2),
+//   disc' = h^2 + (s + w),  w = r^2 - |c|^2 + slack  (1 add, 1 fma), compare.
+// |c|^2 - 2 o.c + |o|^2 cancels catastrophically, so this form only FILTERS: the slacks (2^-17 (|c|^2 + r^2) in w,
+// 2^-17 |o|^2 in the starting value) exceed its rounding error plus that of the exact test, so every sphere the
+// exact test accepts reaches on_candidate(position), where it is tested exactly.
+template <typename OnCandidate>
+__device__ __forceinline__ void scan_expanded(const float4* __restrict__ filter_geom, int32_t n_padded, const PathRay& ray,
+                                              OnCandidate&& on_candidate) {
+    const float dx = ray.d.x, dy = ray.d.y, dz = ray.d.z;
+    const float ox2 = 2.f * ray.o.x, oy2 = 2.f * ray.o.y, oz2 = 2.f * ray.o.z;
+    const float ndo = -dot(ray.d, ray.o);
+    const float oo = dot(ray.o, ray.o);
+    const float noo = fmaf(oo, 7.62939453125e-6f, -oo);
+    for (int32_t k = 0; k < n_padded; k += kUnroll) {
+        float dv[kUnroll];
+#pragma unroll
+        for (int32_t u = 0; u < kUnroll; ++u) {
+            const float4 s = filter_geom[k + u]; // cx, cy, cz, w: scalar loads
+            const float h = fmaf(dz, s.z, fmaf(dy, s.y, fmaf(dx, s.x, ndo)));
+            const float q = fmaf(oz2, s.z, fmaf(oy2, s.y, fmaf(ox2, s.x, noo))) + s.w;
+            dv[u] = fmaf(h, h, q);
+        }
+#pragma unroll
+        for (int32_t u = 0; u < kUnroll; ++u)
+            if (dv[u] >= 0.f) on_candidate(k + u);
+    }
+}
+
+// The expanded-form filter with its sphere operands split between the two sources so that neither limits the
+// VALU: cx, cy come from LDS (wave-uniform ds_read_b128 = two spheres), cz and w through scalar loads.  An
+// SGPR-sourced operation costs ~3.6 cycles of the SIMD's scalar-operand path against 2.2 cycles of ALU time per
+// operation; with 3 of the 9 operations per test SGPR-sourced (10.8 cycles) the ALU (19.5 cycles) stays the bound,
+// and the LDS moves 8 bytes per test instead of 16.
+template <typename OnCandidate>
+__device__ __forceinline__ void scan_hybrid(const float4* lds_xy, const float4* __restrict__ filter_zw, int32_t n_padded,
+                                            const PathRay& ray, OnCandidate&& on_candidate) {
+    const float dx = ray.d.x, dy = ray.d.y, dz = ray.d.z;
+    const float ox2 = 2.f * ray.o.x, oy2 = 2.f * ray.o.y, oz2 = 2.f * ray.o.z;
+    const float ndo = -dot(ray.d, ray.o);
+    const float oo = dot(ray.o, ray.o);
+    const float noo = fmaf(oo, 7.62939453125e-6f, -oo);
+    for (int32_t k = 0; k < n_padded; k += kUnroll) {
+        float dv[kUnroll];
+#pragma unroll
+        for (int32_t u = 0; u < kUnroll; u += 2) {
+            const float4 xy = lds_xy[(k + u) >> 1];        // cx0, cy0, cx1, cy1 (LDS broadcast)
+            const float4 zw = filter_zw[(k + u) >> 1];     // cz0, w0, cz1, w1 (scalar load)
+            const float h0 = fmaf(dz, zw.x, fmaf(dy, xy.y, fmaf(dx, xy.x, ndo)));
+            const float q0 = fmaf(oz2, zw.x, fmaf(oy2, xy.y, fmaf(ox2, xy.x, noo))) + zw.y;
+            dv[u] = fmaf(h0, h0, q0);
+            const float h1 = fmaf(dz, zw.z, fmaf(dy, xy.w, fmaf(dx, xy.z, ndo)));
+            const float q1 = fmaf(oz2, zw.z, fmaf(oy2, xy.w, fmaf(ox2, xy.z, noo))) + zw.w;
+            dv[u + 1] = fmaf(h1, h1, q1);
+        }
+#pragma unroll
+        for (int32_t u = 0; u < kUnroll; ++u)
+            if (dv[u] >= 0.f) on_candidate(k + u);
+    }
+}
+
 constexpr int kPoolItems = 64; // work items a wave takes from the global queue per atomic
-constexpr int kQueueCap = 16; // per-lane candidate slots in LDS (variants 2, 3)
+constexpr int kQueueCap = 16;
+constexpr int kTrStride = 9;  // floats per ray in the operand staging rows of the matrix-core scan (odd: no bank conflicts)
+typedef float f32x4 __attribute__((ext_vector_type(4))); // per-lane candidate slots in LDS (variants 2, 3)
 
 template <int VARIANT>
-__global__ __launch_bounds__(256) void render_f32_kernel(
-    CamDev<float> cam, const float4* __restrict__ narrow_geom, const v2f* __restrict__ narrow_pairs,
-    const int32_t* __restrict__ narrow_index,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void render_f32_kernel(
+    CamDev<float> cam, const float4* __restrict__ narrow_geom, const float4* __restrict__ filter_geom,
+    const float4* __restrict__ filter_zw,
+    const v2f* __restrict__ narrow_pairs,
+    const int32_t* __restrict__ narrow_index, const float* __restrict__ narrow_tiles, int32_t n_tiles,
     int32_t n_narrow_padded, const int32_t* __restrict__ wide_index, int32_t n_wide,
     const double* __restrict__ geom64, const float4* __restrict__ geom32, const float4* __restrict__ mat32,
     const uint32_t* __restrict__ kind, Partition part, RngKey key, int32_t samples_per_item, int32_t n_chunks,
     unsigned long long n_items, unsigned long long* __restrict__ accum, DeviceCounters* counters) {
     const int lane = __lane_id();
     const long long npix = (long long)part.n_rows * cam.W;
+    extern __shared__ float4 lds_geom[]; // VARIANT 7: the narrow-sphere table, staged once per block
+    if constexpr (VARIANT == 7) {
+        for (int32_t k = threadIdx.x; k < n_narrow_padded; k += blockDim.x) lds_geom[k] = narrow_geom[k];
+        __syncthreads();
+    }
+    if constexpr (VARIANT == 8) { // cx, cy of two consecutive spheres of the filter table per float4
+        for (int32_t k = threadIdx.x; k < n_narrow_padded / 2; k += blockDim.x) {
+            const float4 a = filter_geom[2 * k], b = filter_geom[2 * k + 1];
+            lds_geom[k] = make_float4(a.x, a.y, b.x, b.y);
+        }
+        __syncthreads();
+    }
 
     bool alive = false, done = false, have_item = false;
     int32_t s_next = 0, s_end = 0;
@@ -264,19 +369,128 @@ __global__ __launch_bounds__(256) void render_f32_kernel(
         }
         if (__ballot(alive) == 0ull) break;
 
+        [[maybe_unused]] uint32_t n_listed = 0;
+        [[maybe_unused]] const uint32_t* my_list = nullptr;
+        if constexpr (VARIANT == 5) {
+            // ---- matrix-core filter -------------------------------------------------------------------
+            // The line-sphere discriminant in expanded form is two rays x spheres products with K = 4:
+            //   H = [dx dy dz -d.o] . [cx cy cz 1]            Q = [2ox 2oy 2oz 1] . [cx cy cz w] + cinit
+            //   w = r^2 - |c|^2 + slack_c,  cinit = -|o|^2 + slack_o,   filter: H^2 + Q >= 0
+            // The expanded form cancels badly, so it only FILTERS: the slacks (2^-17 (|c|^2 + r^2) and
+            // 2^-17 |o|^2) exceed its rounding error plus that of the exact f32 test, hence every sphere the
+            // exact test would accept is listed, and listed spheres are then tested exactly as in the other
+            // variants.  16 rays x 16 spheres per v_mfma_f32_16x16x4_f32; the matrix pipe works beside the VALU.
+            __shared__ float tr[256 * kTrStride];
+            __shared__ uint32_t cand_cnt[256];
+            __shared__ uint32_t cand_list[kQueueCap * 256];
+            const int tid = threadIdx.x, wbase = tid & ~63;
+            {
+                float* row = tr + tid * kTrStride;
+                const float oo = dot(ray.o, ray.o);
+                row[0] = ray.d.x; row[1] = ray.d.y; row[2] = ray.d.z; row[3] = -dot(ray.d, ray.o);
+                row[4] = 2.f * ray.o.x; row[5] = 2.f * ray.o.y; row[6] = 2.f * ray.o.z; row[7] = 1.f;
+                row[8] = alive ? fmaf(oo, 7.62939453125e-6f, -oo) : -1e30f; // a dead lane's ray lists nothing
+                cand_cnt[tid] = 0u;
+            }
+            __builtin_amdgcn_wave_barrier(); // a wave's LDS operations complete in order; the waves are independent
+            const int r16 = lane & 15, kq = lane >> 4;
+            float aH[4], aQ[4];
+            f32x4 cin[4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const float* src = tr + (wbase + 16 * b + r16) * kTrStride; // A[row = lane&15][k = lane>>4]
+                aH[b] = src[kq];
+                aQ[b] = src[4 + kq];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) cin[b][g] = tr[(wbase + 16 * b + 4 * kq + g) * kTrStride + 8]; // C row = 4*(lane>>4)+g
+            }
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+            float bq = narrow_tiles[lane]; // B[k = lane>>4][col = lane&15]: lanes 0-15 cx, 16-31 cy, 32-47 cz, 48-63 w
+            for (int32_t t = 0; t < n_tiles; ++t) {
+                const float bq_next = narrow_tiles[(size_t)(t + 1) * 64 + lane]; // the table ends with a spare tile
+                const float bh = kq == 3 ? 1.f : bq;
+                f32x4 d[4];
+                float m = -INFINITY;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const f32x4 hh = __builtin_amdgcn_mfma_f32_16x16x4f32(aH[b], bh, zero, 0, 0, 0);
+                    const f32x4 qq = __builtin_amdgcn_mfma_f32_16x16x4f32(aQ[b], bq, cin[b], 0, 0, 0);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        d[b][g] = fmaf(hh[g], hh[g], qq[g]);
+                        m = fmaxf(m, d[b][g]);
+                    }
+                }
+                if (__ballot(m >= 0.f) != 0ull) { // rare: some ray of the wave may meet some sphere of the tile
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g)
+                            if (d[b][g] >= 0.f) {
+                                const int slot = wbase + 16 * b + 4 * kq + g; // the ray's lane
+                                const uint32_t n = atomicAdd(&cand_cnt[slot], 1u);
+                                if (n < (uint32_t)kQueueCap) cand_list[n * 256 + slot] = (uint32_t)(t * 16 + r16);
+                            }
+                }
+                bq = bq_next;
+            }
+            __builtin_amdgcn_wave_barrier();
+            n_listed = cand_cnt[tid];
+            my_list = cand_list + tid;
+        }
+
         if (alive) {
             // ---- closest hit over the sphere list: hittable_list.rs:60-74 -----------------------
             n_seg++;
             const float ox = ray.o.x, oy = ray.o.y, oz = ray.o.z, dx = ray.d.x, dy = ray.d.y, dz = ray.d.z;
             const float tmin = ray.tmin;
             ScanBest sb = {INFINITY, -1, false};
-            if constexpr (VARIANT == 0 || VARIANT == 1 || VARIANT == 4) {
+            if constexpr (VARIANT == 0 || VARIANT == 1 || VARIANT == 4 || VARIANT == 7) {
                 // roots evaluated where the candidate is found
                 auto accept = [&](float h, float disc, int32_t pos) { scan_accept(sb, h, disc, tmin, pos); };
                 if constexpr (VARIANT == 1)
                     scan_packed(narrow_pairs, n_narrow_padded, ray, accept);
+                else if constexpr (VARIANT == 7)
+                    scan_lds(lds_geom, n_narrow_padded, ray, accept);
                 else
                     scan_plain<VARIANT == 4>(narrow_geom, n_narrow_padded, ray, accept);
+            } else if constexpr (VARIANT == 8) {
+                auto exact = [&](int32_t pos) {
+                    const float4 s = narrow_geom[pos];
+                    const float ocx = s.x - ox, ocy = s.y - oy, ocz = s.z - oz;
+                    const float h = fmaf(ocz, dz, fmaf(ocy, dy, ocx * dx));
+                    const float qq = fmaf(-ocz, ocz, fmaf(-ocy, ocy, fmaf(-ocx, ocx, s.w)));
+                    const float disc = fmaf(h, h, qq);
+                    if (disc >= 0.f) scan_accept(sb, h, disc, tmin, pos);
+                };
+                scan_hybrid(lds_geom, filter_zw, n_narrow_padded, ray, exact);
+            } else if constexpr (VARIANT == 6) {
+                auto exact = [&](int32_t pos) { // the test of the other variants, on the spheres the filter lets through
+                    const float4 s = narrow_geom[pos];
+                    const float ocx = s.x - ox, ocy = s.y - oy, ocz = s.z - oz;
+                    const float h = fmaf(ocz, dz, fmaf(ocy, dy, ocx * dx));
+                    const float qq = fmaf(-ocz, ocz, fmaf(-ocy, ocy, fmaf(-ocx, ocx, s.w)));
+                    const float disc = fmaf(h, h, qq);
+                    if (disc >= 0.f) scan_accept(sb, h, disc, tmin, pos);
+                };
+                scan_expanded(filter_geom, n_narrow_padded, ray, exact);
+            } else if constexpr (VARIANT == 5) {
+                auto exact = [&](int32_t pos) {
+                    const float4 s = narrow_geom[pos];
+                    const float ocx = s.x - ox, ocy = s.y - oy, ocz = s.z - oz;
+                    const float h = fmaf(ocz, dz, fmaf(ocy, dy, ocx * dx));
+                    const float qq = fmaf(-ocz, ocz, fmaf(-ocy, ocy, fmaf(-ocx, ocx, s.w)));
+                    const float disc = fmaf(h, h, qq);
+                    if (disc >= 0.f) scan_accept<true>(sb, h, disc, tmin, pos);
+                };
+                const bool overflow = n_listed > (uint32_t)kQueueCap;
+                if (overflow) { // more candidates than list slots: this ray scans every sphere exactly
+                    auto accept = [&](float h, float disc, int32_t pos) { scan_accept(sb, h, disc, tmin, pos); };
+                    scan_plain<false>(narrow_geom, n_narrow_padded, ray, accept);
+                }
+                const uint32_t n_mine = overflow ? 0u : n_listed;
+                for (uint32_t q = 0; __ballot(q < n_mine) != 0ull; ++q)
+                    if (q < n_mine) exact((int32_t)my_list[q * 256]);
             } else {
                 // candidates are only recorded during the scan (one LDS store each) and their roots are
                 // evaluated afterwards, each lane walking its own short list; slot s of a lane is word
@@ -463,16 +677,28 @@ __global__ __launch_bounds__(256) void resolve_f32_kernel(int32_t W, int32_t spp
 } // namespace
 
 F32Plan plan_render_f32(const CamDev<float>& cam, const Partition& part, int32_t samples_per_item, int32_t variant,
-                        int device) {
+                        int32_t n_narrow_padded, int device) {
     F32Plan plan{};
     plan.variant = variant;
+    plan.lds_bytes = variant == 7 ? (size_t)n_narrow_padded * 16u : variant == 8 ? (size_t)n_narrow_padded * 8u : 0u;
     plan.block = 256;
     int cus = 256, per_cu = 4;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
     int occ = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, render_f32_kernel<0>, plan.block, 0) == hipSuccess && occ > 0)
-        per_cu = occ;
+    hipError_t oe = hipErrorUnknown;
+    switch (variant) {
+    case 1: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, render_f32_kernel<1>, plan.block, 0); break;
+    case 2: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, render_f32_kernel<2>, plan.block, 0); break;
+    case 3: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, render_f32_kernel<3>, plan.block, 0); break;
+    case 4: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, render_f32_kernel<4>, plan.block, 0); break;
+    case 5: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, render_f32_kernel<5>, plan.block, 0); break;
+    case 6: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, render_f32_kernel<6>, plan.block, 0); break;
+    case 7: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, render_f32_kernel<7>, plan.block, plan.lds_bytes); break;
+    case 8: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, render_f32_kernel<8>, plan.block, plan.lds_bytes); break;
+    default: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, render_f32_kernel<0>, plan.block, 0); break;
+    }
+    if (oe == hipSuccess && occ > 0) per_cu = occ;
     plan.grid = cus * per_cu;
     const long long npix = (long long)part.n_rows * cam.W;
     const long long lanes = (long long)plan.grid * plan.block;
@@ -504,8 +730,14 @@ hipError_t launch_render_f32(const CamDev<float>& cam, const SceneDev& scene, co
     if (plan.variant == 2) kern = render_f32_kernel<2>;
     if (plan.variant == 3) kern = render_f32_kernel<3>;
     if (plan.variant == 4) kern = render_f32_kernel<4>;
-    hipLaunchKernelGGL(kern, dim3(plan.grid), dim3(plan.block), 0, stream, cam, (const float4*)scene.narrow_geom,
-                       (const v2f*)scene.narrow_pairs, scene.narrow_index, scene.n_narrow_padded, scene.wide_index,
+    if (plan.variant == 5) kern = render_f32_kernel<5>;
+    if (plan.variant == 6) kern = render_f32_kernel<6>;
+    if (plan.variant == 7) kern = render_f32_kernel<7>;
+    if (plan.variant == 8) kern = render_f32_kernel<8>;
+    hipLaunchKernelGGL(kern, dim3(plan.grid), dim3(plan.block), plan.lds_bytes, stream, cam, (const float4*)scene.narrow_geom,
+                       (const float4*)scene.filter_geom, (const float4*)scene.filter_zw,
+                       (const v2f*)scene.narrow_pairs, scene.narrow_index, scene.narrow_tiles, scene.n_tiles,
+                       scene.n_narrow_padded, scene.wide_index,
                        scene.n_wide, scene.geom64, (const float4*)scene.geom32, (const float4*)scene.mat32, scene.kind,
                        part, key, plan.samples_per_item, plan.n_chunks, n_items, d_accum, d_counters);
     return hipGetLastError();

@@ -178,7 +178,7 @@ def test_f32_scan_variants_agree(dray, gpu):
     cam = dray.camera_final(width=96, spp=12, depth=50)
     cam.mode = dray.MODE_F32
     a = render_gpu(dray, gpu, spheres, cam, seed=13, variant=0)
-    for v in (1, 2, 3, 4):
+    for v in (1, 2, 3, 4, 5, 6, 7, 8):
         b = render_gpu(dray, gpu, spheres, cam, seed=13, variant=v)
         assert (a[0] == b[0]).all() and (a[1] == b[1]).all() and a[3].segments == b[3].segments, v
 
