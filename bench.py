@@ -60,7 +60,7 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--mode", default="f32", choices=["f32", "f64", "f32plain"])
     ap.add_argument("--samples-per-item", type=int, default=0)
-    ap.add_argument("--variant", type=int, default=0, help="f32 scan formulation (A/B builds); 0 = library default")
+    ap.add_argument("--variant", type=int, default=0, help="f32 sphere-scan formulation: 0 auto, 1 scalar, 2 hybrid (identical images)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 

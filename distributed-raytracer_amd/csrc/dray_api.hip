@@ -139,7 +139,8 @@ void scene_free(dray_scene* s) {
     SceneDev& d = s->dev;
     (void)hipFree(d.geom64); (void)hipFree(d.mat64); (void)hipFree(d.kind);
     (void)hipFree(d.geom32); (void)hipFree(d.mat32);
-    (void)hipFree(d.narrow_geom); (void)hipFree(d.narrow_pairs); (void)hipFree(d.narrow_tiles); (void)hipFree(d.filter_geom); (void)hipFree(d.filter_zw); (void)hipFree(d.narrow_index); (void)hipFree(d.wide_index);
+    (void)hipFree(d.narrow_geom); (void)hipFree(d.filter_xy); (void)hipFree(d.filter_zn);
+    (void)hipFree(d.narrow_index); (void)hipFree(d.wide_index);
     (void)hipFree(s->d_counters); (void)hipFree(s->d_accum);
     for (auto& e : s->ev)
         if (e) (void)hipEventDestroy(e);
@@ -206,44 +207,41 @@ int scene_create_impl(const dray_sphere* sp, size_t n, int32_t device, dray_scen
         ng.push_back(0.f); ng.push_back(0.f); ng.push_back(0.f); ng.push_back(-1e30f);
     }
     d.n_narrow_padded = (int32_t)nidx.size();
-    std::vector<float> np(ng.size());
-    for (size_t p = 0; p + 1 < nidx.size(); p += 2)
-        for (int q = 0; q < 4; ++q) {
-            np[4 * p + 2 * q + 0] = ng[4 * p + q];
-            np[4 * p + 2 * q + 1] = ng[4 * (p + 1) + q];
-        }
-
-    // tiles for the matrix-core filter; unused slots hold a sphere no ray can list (w = -1e30)
-    d.n_tiles = (int32_t)((d.n_narrow + 15) / 16);
-    std::vector<float> tiles((size_t)(d.n_tiles + 1) * 64, 0.f);
-    for (size_t t = 0; t < (size_t)d.n_tiles + 1; ++t)
-        for (int q = 0; q < 16; ++q) tiles[t * 64 + 48 + q] = -1e30f;
-    std::vector<float> fg(ng.size(), 0.f); // the scan table with w in place of r^2; padding entries are never listed
-    for (size_t p = (size_t)d.n_narrow; p < nidx.size(); ++p) fg[4 * p + 3] = -1e30f;
-    for (int32_t p = 0; p < d.n_narrow; ++p) {
-        const float cx = ng[4 * p + 0], cy = ng[4 * p + 1], cz = ng[4 * p + 2], r2 = ng[4 * p + 3];
-        const double c2 = (double)cx * cx + (double)cy * cy + (double)cz * cz;
-        const double w = (double)r2 - c2 + 7.62939453125e-6 * (c2 + (double)r2); // slack 2^-17 (|c|^2 + r^2)
-        float wf = (float)w;
-        if ((double)wf < w) wf = std::nextafterf(wf, INFINITY); // round towards listing
-        fg[4 * p + 0] = cx; fg[4 * p + 1] = cy; fg[4 * p + 2] = cz; fg[4 * p + 3] = wf;
-        float* tile = &tiles[(size_t)(p / 16) * 64];
-        tile[p % 16] = cx; tile[16 + p % 16] = cy; tile[32 + p % 16] = cz; tile[48 + p % 16] = wf;
-    }
-
-    std::vector<float> fzw(fg.size() / 2);
+    // Filter tables of the hybrid scan: per two consecutive narrow spheres (cx0, cy0, cx1, cy1) and
+    // (cz0, nw0, cz1, nw1) with nw = |c|^2 - r^2 - 2^-17 (|c|^2 + r^2), rounded towards listing (downwards).
+    std::vector<float> fxy(2 * nidx.size()), fzn(2 * nidx.size());
     for (size_t p = 0; p < nidx.size(); ++p) {
-        fzw[2 * p + 0] = fg[4 * p + 2];
-        fzw[2 * p + 1] = fg[4 * p + 3];
+        const float cx = ng[4 * p + 0], cy = ng[4 * p + 1], cz = ng[4 * p + 2], r2 = ng[4 * p + 3];
+        float nwf = 1e30f; // padding: never listed
+        if ((int32_t)p < d.n_narrow) {
+            const double c2 = (double)cx * cx + (double)cy * cy + (double)cz * cz;
+            const double nw = c2 - (double)r2 - 7.62939453125e-6 * (c2 + (double)r2);
+            nwf = (float)nw;
+            if ((double)nwf > nw) nwf = std::nextafterf(nwf, -INFINITY);
+        }
+        fxy[2 * p + 0] = cx; fxy[2 * p + 1] = cy;
+        fzn[2 * p + 0] = cz; fzn[2 * p + 1] = nwf;
     }
 
     int rc = DRAY_OK;
     if ((rc = upload(&d.geom64, g64)) || (rc = upload(&d.mat64, m64)) || (rc = upload(&d.kind, kind)) ||
-        (rc = upload(&d.geom32, g32)) || (rc = upload(&d.mat32, m32)) || (rc = upload(&d.narrow_geom, ng)) || (rc = upload(&d.narrow_pairs, np)) || (rc = upload(&d.narrow_tiles, tiles)) || (rc = upload(&d.filter_geom, fg)) || (rc = upload(&d.filter_zw, fzw)) ||
+        (rc = upload(&d.geom32, g32)) || (rc = upload(&d.mat32, m32)) || (rc = upload(&d.narrow_geom, ng)) ||
+        (rc = upload(&d.filter_xy, fxy)) || (rc = upload(&d.filter_zn, fzn)) ||
         (rc = upload(&d.narrow_index, nidx)) || (rc = upload(&d.wide_index, widx))) {
         scene_free(s);
         return rc;
     }
+    d.f32.narrow_geom = (const float4*)d.narrow_geom;
+    d.f32.filter_xy = (const float4*)d.filter_xy;
+    d.f32.filter_zn = (const float4*)d.filter_zn;
+    d.f32.narrow_index = d.narrow_index;
+    d.f32.wide_index = d.wide_index;
+    d.f32.geom64 = d.geom64;
+    d.f32.geom32 = (const float4*)d.geom32;
+    d.f32.mat32 = (const float4*)d.mat32;
+    d.f32.kind = d.kind;
+    d.f32.n_narrow_padded = d.n_narrow_padded;
+    d.f32.n_wide = d.n_wide;
     hipError_t e = hipMalloc((void**)&s->d_counters, sizeof(DeviceCounters));
     for (auto& ev : s->ev)
         if (e == hipSuccess) e = hipEventCreate(&ev);
@@ -261,7 +259,7 @@ int render_device_impl(const dray_camera* cam, dray_scene* scene, uint32_t* d_co
     if (!camera_ok(cam) || !scene || !d_color) return DRAY_ERR_INVALID_ARG;
     dray_opts opts;
     if (opts_in) opts = *opts_in; else dray_opts_default(&opts);
-    if (opts.mode > DRAY_MODE_F32_PLAIN) return DRAY_ERR_INVALID_ARG;
+    if (opts.mode > DRAY_MODE_F32_PLAIN || opts.variant < 0 || opts.variant > DRAY_SCAN_HYBRID) return DRAY_ERR_INVALID_ARG;
     if (opts.row_step == 0) opts.row_step = 1;
     if (opts.row_step < 0 || opts.row_begin < 0) return DRAY_ERR_INVALID_ARG;
     if (opts.device >= 0 && opts.device != scene->device) return DRAY_ERR_INVALID_ARG;

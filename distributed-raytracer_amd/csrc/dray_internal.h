@@ -30,7 +30,23 @@ struct RngKey {
     uint32_t k0, k1, sample_offset;
 };
 
-// Sphere tables in device memory.
+// What the f32 throughput kernel reads (device pointers, handed to the kernel one by one).
+// "Narrow" spheres are scanned in f32, "wide" ones (large radius) are intersected in f64.
+struct F32Tables {
+    const float4* narrow_geom = nullptr;  // n_narrow_padded: cx, cy, cz, r*r, insertion order; padding never hits
+    const float4* filter_xy = nullptr;    // n_narrow_padded/2: cx0, cy0, cx1, cy1 of two consecutive narrow spheres
+    const float4* filter_zn = nullptr;    // n_narrow_padded/2: cz0, nw0, cz1, nw1; nw = |c|^2 - r^2 - 2^-17 (|c|^2 + r^2)
+    const int32_t* narrow_index = nullptr; // position of a narrow sphere in the caller's list
+    const int32_t* wide_index = nullptr;   // positions of the wide spheres, ascending
+    const double* geom64 = nullptr;        // n x 4: cx, cy, cz, radius
+    const float4* geom32 = nullptr;        // n: cx, cy, cz, radius
+    const float4* mat32 = nullptr;         // n: albedo rgb, fuzz or refraction index
+    const uint32_t* kind = nullptr;        // n: material kind
+    int32_t n_narrow_padded = 0;
+    int32_t n_wide = 0;
+};
+
+// Sphere tables in device memory (owned by the scene).
 struct SceneDev {
     int32_t n = 0;
     // f64 tables (reference-order kernels)
@@ -40,20 +56,16 @@ struct SceneDev {
     // f32 tables (throughput and f32-plain kernels)
     float* geom32 = nullptr; // n x 4: cx, cy, cz, radius
     float* mat32 = nullptr;  // n x 4
-    // throughput kernel: "narrow" spheres are scanned in f32, "wide" ones (large radius) in f64
-    int32_t n_narrow = 0, n_wide = 0;
-    float* narrow_geom = nullptr;    // n_narrow_padded x 4: cx, cy, cz, r*r  (padding never hits)
-    float* filter_geom = nullptr;    // n_narrow_padded x 4: cx, cy, cz, w = r^2 - |c|^2 + slack (expanded-form filter)
-    float* filter_zw = nullptr;      // n_narrow_padded/2 x 4: cz0, w0, cz1, w1 of the filter table
-    float* narrow_pairs = nullptr;   // the same table as pairs: (cx0,cx1),(cy0,cy1),(cz0,cz1),(r0^2,r1^2)
-    int32_t* narrow_index = nullptr; // position in the caller's list
-    // matrix-core filter: tiles of 16 narrow spheres, 64 floats each: cx[16] cy[16] cz[16] w[16], w = r^2-|c|^2+slack,
-    // plus one spare tile at the end (the kernel prefetches one tile ahead)
-    float* narrow_tiles = nullptr;
-    int32_t n_tiles = 0;
-    int32_t n_narrow_padded = 0;
-    int32_t* wide_index = nullptr; // positions of the wide spheres, ascending
+    int32_t n_narrow = 0, n_wide = 0, n_narrow_padded = 0;
+    float* narrow_geom = nullptr;
+    float* filter_xy = nullptr;
+    float* filter_zn = nullptr;
+    int32_t* narrow_index = nullptr;
+    int32_t* wide_index = nullptr;
+    F32Tables f32; // the pointers above, as the f32 kernel takes them
 };
+
+constexpr size_t kHybridLdsLimit = 64 * 1024; // largest cx,cy table (8 B per sphere) the hybrid scan stages in LDS
 
 struct DeviceCounters {
     unsigned long long segments;
@@ -76,8 +88,8 @@ struct F32Plan {
     int32_t n_chunks;         // ceil(spp / samples_per_item)
     size_t accum_words;       // 3 * n_rows * W fixed-point sums (u64), zeroed before the launch
     int32_t grid, block;
-    size_t lds_bytes; // dynamic LDS of the launch
-    int32_t variant; // scan formulation: 0 one sphere per instruction, 1 two spheres per packed-f32 instruction
+    size_t lds_bytes;         // dynamic LDS of the launch
+    int32_t hybrid;           // 1: filter + exact scan with the filter table in LDS, 0: exact scan through scalar loads
 };
 F32Plan plan_render_f32(const CamDev<float>& cam, const Partition& part, int32_t samples_per_item, int32_t variant,
                         int32_t n_narrow_padded, int device);

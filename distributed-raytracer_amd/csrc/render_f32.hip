@@ -4,8 +4,8 @@
 // reference's ray_color (src/raytracer/camera.rs:264-282) is the iterative
 // bounce loop of its twin ray_color_iteration (camera.rs:118-144) with an
 // explicit throughput.  When a lane's path ends it starts the next sample of
-// its work item, and when the item is used up the wave draws new items from a
-// global queue, so all 64 lanes stay inside the sphere scan, which is the same
+// its work item, and when the item is used up it takes the next item of the
+// wave's pool, so all 64 lanes stay inside the sphere scan, which is the same
 // instruction stream for every lane whatever its pixel, sample or bounce.
 //
 // A work item is `samples_per_item` consecutive samples of one pixel.  Sample
@@ -14,10 +14,16 @@
 // the GPU count or the order in which lanes finish.
 //
 // The sphere list is scanned in insertion order (hittable_list.rs:65-70).
-// "Narrow" spheres are tested in f32 with the geometry arriving through scalar
-// loads (the address is the same for all lanes); "wide" spheres, whose radius is
-// so large that |oc|^2 - r^2 cancels catastrophically in f32 (the 1000-radius
-// ground of src/main.rs:14), are tested in f64.
+// "Narrow" spheres are tested in f32; "wide" spheres, whose radius is so large
+// that |oc|^2 - r^2 cancels catastrophically in f32 (the 1000-radius ground of
+// src/main.rs:14), are tested in f64.
+//
+// What bounds the scan on this chip (tools/ubench_operand.hip, tools/ubench_valu.hip): a VALU operation whose
+// operands are all VGPRs costs ~2.2 cycles of a SIMD, one with an SGPR (or DPP) operand ~3.6 cycles of the
+// SIMD's scalar-operand path, and the two overlap; packed f32 halves the instruction count but not the ALU
+// cycles; f32 matrix instructions run on the same ALUs.  So the scan minimises VGPR-only ALU operations per
+// ray-sphere test and keeps the SGPR-sourced ones under ~60 % of the mix (scan_hybrid below: 8 operations, 3
+// of them SGPR-sourced, against 11 and 4 for the direct form of sphere.rs:29-36).
 #include "dray_device.h"
 #include "dray_internal.h"
 
@@ -27,7 +33,9 @@ namespace {
 constexpr float kFixScale = 268435456.f;      // 2^28
 constexpr double kFixInv = 1.0 / 268435456.0; // 2^-28
 constexpr float kFixMax = 15.99f;             // a sample colour channel is clamped to [0, 15.99]
-constexpr int kUnroll = 8;
+constexpr int kUnroll = 8;                    // spheres per scan block (the tables are padded to a multiple)
+constexpr int kPoolItems = 64;                // work items a wave takes from the global queue per atomic
+constexpr float kSlack = 7.62939453125e-6f;   // 2^-17, see scan_hybrid
 
 struct F3 {
     float x, y, z;
@@ -94,216 +102,106 @@ __device__ __forceinline__ uint32_t to_fixed(float c) {
     return (uint32_t)(fminf(fmaxf(c, 0.f), kFixMax) * kFixScale);
 }
 
-typedef float v2f __attribute__((ext_vector_type(2)));
-
 struct ScanBest {
-    float t;      // closest accepted root so far (INFINITY: none)
-    int32_t pos;  // its position in the narrow table, -1: none
-    bool far;     // the far root was the accepted one
+    float t;     // closest accepted root so far (INFINITY: none)
+    int32_t pos; // its position in the narrow table, -1: none
+    bool far;    // the far root was the accepted one
 };
 
-// TIE: candidates may arrive out of insertion order, so on equal t the earlier sphere is kept explicitly
-// (hittable_list.rs:65-70); in an in-order scan the strict comparison alone does that.
-template <bool TIE = false>
-__device__ __forceinline__ void scan_accept(ScanBest& b, float h, float disc, float tmin, int32_t pos) { // sphere.rs:40-48
-    const float sq = fsqrt(disc);
-    const float t0 = h - sq;
-    const bool far = !(t0 > tmin);
-    const float t = far ? h + sq : t0;
-    if (t > tmin && (t < b.t || (TIE && t == b.t && pos < b.pos))) {
-        b.t = t;
-        b.pos = pos;
-        b.far = far;
+// The exact f32 test of one narrow sphere, sphere.rs:29-48 with |d| = 1: disc = h^2 - (|oc|^2 - r^2).
+// geom = cx, cy, cz, r^2.
+__device__ __forceinline__ void exact_test(ScanBest& b, const float4 s, const PathRay& ray, int32_t pos) {
+    const float ocx = s.x - ray.o.x, ocy = s.y - ray.o.y, ocz = s.z - ray.o.z;
+    const float h = fmaf(ocz, ray.d.z, fmaf(ocy, ray.d.y, ocx * ray.d.x));
+    const float q = fmaf(-ocz, ocz, fmaf(-ocy, ocy, fmaf(-ocx, ocx, s.w)));
+    const float disc = fmaf(h, h, q);
+    if (disc >= 0.f) {
+        const float sq = fsqrt(disc);
+        const float t0 = h - sq;
+        const bool far = !(t0 > ray.tmin);
+        const float t = far ? h + sq : t0;
+        if (t > ray.tmin && t < b.t) { // interval.rs:28-30; strict: on equal t the earlier sphere stays
+            b.t = t;
+            b.pos = pos;
+            b.far = far;
+        }
     }
 }
 
-// The scan visits the narrow spheres in insertion order and calls on_candidate(h, disc, position) for every
-// sphere whose line-sphere discriminant is non-negative (sphere.rs:29-36 with |d| = 1:
-// disc = h^2 - (|oc|^2 - r^2)).  The table address is the same for all lanes, so the geometry arrives through
-// scalar loads (two s_load_dwordx16 per 8 spheres) and feeds the VALU as scalar operands.
-
-// One sphere per VALU instruction.  BLOCK_TEST: one max over the 8 discriminants decides whether any lane has a
-// candidate in the block at all (candidates are rare), replacing 8 compare-and-branch sequences by one.
-template <bool BLOCK_TEST, typename OnCandidate>
-__device__ __forceinline__ void scan_plain(const float4* __restrict__ narrow_geom, int32_t n_padded, const PathRay& ray,
-                                           OnCandidate&& on_candidate) {
-    const float ox = ray.o.x, oy = ray.o.y, oz = ray.o.z, dx = ray.d.x, dy = ray.d.y, dz = ray.d.z;
+// Scalar scan: the exact test on every sphere, 11 VALU operations per test of which 4 take an SGPR operand.
+// The table address is the same for all lanes, so the geometry arrives through scalar loads (two
+// s_load_dwordx16 per 8 spheres).  Used when the filter table does not fit in LDS, and as the A/B baseline.
+__device__ __forceinline__ void scan_scalar(const float4* __restrict__ narrow_geom, int32_t n_padded, const PathRay& ray,
+                                            ScanBest& b) {
     for (int32_t k = 0; k < n_padded; k += kUnroll) {
-        float hv[kUnroll], dv[kUnroll];
 #pragma unroll
-        for (int32_t u = 0; u < kUnroll; ++u) {
-            const float4 s = narrow_geom[k + u];
-            const float ocx = s.x - ox, ocy = s.y - oy, ocz = s.z - oz;
-            hv[u] = fmaf(ocz, dz, fmaf(ocy, dy, ocx * dx));
-            const float q = fmaf(-ocz, ocz, fmaf(-ocy, ocy, fmaf(-ocx, ocx, s.w)));
-            dv[u] = fmaf(hv[u], hv[u], q);
-        }
-        if constexpr (BLOCK_TEST) {
-            float m = dv[0];
-#pragma unroll
-            for (int32_t u = 1; u < kUnroll; ++u) m = fmaxf(m, dv[u]);
-            if (!(m >= 0.f)) continue;
-        }
-#pragma unroll
-        for (int32_t u = 0; u < kUnroll; ++u)
-            if (dv[u] >= 0.f) on_candidate(hv[u], dv[u], k + u);
+        for (int32_t u = 0; u < kUnroll; ++u) exact_test(b, narrow_geom[k + u], ray, k + u);
     }
 }
 
-// Two spheres per packed-f32 instruction.  The pair table holds, per two consecutive spheres,
-// (cx0,cx1),(cy0,cy1),(cz0,cz1),(r0^2,r1^2); the ray's components are splat into both halves.
-template <typename OnCandidate>
-__device__ __forceinline__ void scan_packed(const v2f* __restrict__ pairs, int32_t n_padded, const PathRay& ray,
-                                            OnCandidate&& on_candidate) {
-    const v2f ox = {ray.o.x, ray.o.x}, oy = {ray.o.y, ray.o.y}, oz = {ray.o.z, ray.o.z};
-    const v2f dx = {ray.d.x, ray.d.x}, dy = {ray.d.y, ray.d.y}, dz = {ray.d.z, ray.d.z};
-    constexpr int kPairs = kUnroll / 2;
-    for (int32_t k = 0; k < n_padded; k += kUnroll) {
-        v2f hv[kPairs], dv[kPairs];
-#pragma unroll
-        for (int32_t u = 0; u < kPairs; ++u) {
-            const v2f* g = pairs + (size_t)(k / 2 + u) * 4;
-            const v2f ocx = g[0] - ox, ocy = g[1] - oy, ocz = g[2] - oz;
-            v2f h = ocx * dx;
-            h = __builtin_elementwise_fma(ocy, dy, h);
-            h = __builtin_elementwise_fma(ocz, dz, h);
-            v2f q = __builtin_elementwise_fma(-ocx, ocx, g[3]);
-            q = __builtin_elementwise_fma(-ocy, ocy, q);
-            q = __builtin_elementwise_fma(-ocz, ocz, q);
-            hv[u] = h;
-            dv[u] = __builtin_elementwise_fma(h, h, q);
-        }
-#pragma unroll
-        for (int32_t u = 0; u < kPairs; ++u) {
-            if (dv[u].x >= 0.f) on_candidate(hv[u].x, dv[u].x, k + 2 * u);
-            if (dv[u].y >= 0.f) on_candidate(hv[u].y, dv[u].y, k + 2 * u + 1);
-        }
-    }
-}
-
-// The scan of scan_plain with the geometry read from LDS instead of through scalar loads.  On gfx950 a VALU
-// operation with an SGPR (or DPP) operand issues at about 3.6 cycles per wave against 2.2 for VGPR-only operands
-// (tools/ubench_operand.hip), and 4 of the 11 operations per test take sphere data.  A wave-uniform ds_read_b128
-// broadcasts one sphere into 4 VGPRs without using the VALU, so all 11 operations become VGPR-only.
-template <typename OnCandidate>
-__device__ __forceinline__ void scan_lds(const float4* lds_geom, int32_t n_padded, const PathRay& ray,
-                                         OnCandidate&& on_candidate) {
-    const float ox = ray.o.x, oy = ray.o.y, oz = ray.o.z, dx = ray.d.x, dy = ray.d.y, dz = ray.d.z;
-    constexpr int kStep = 4;
-    for (int32_t k = 0; k < n_padded; k += kStep) {
-        float hv[kStep], dv[kStep];
-#pragma unroll
-        for (int32_t u = 0; u < kStep; ++u) {
-            const float4 s = lds_geom[k + u];
-            const float ocx = s.x - ox, ocy = s.y - oy, ocz = s.z - oz;
-            hv[u] = fmaf(ocz, dz, fmaf(ocy, dy, ocx * dx));
-            const float q = fmaf(-ocz, ocz, fmaf(-ocy, ocy, fmaf(-ocx, ocx, s.w)));
-            dv[u] = fmaf(hv[u], hv[u], q);
-        }
-#pragma unroll
-        for (int32_t u = 0; u < kStep; ++u)
-            if (dv[u] >= 0.f) on_candidate(hv[u], dv[u], k + u);
-    }
-}
-
-// Expanded-form filter, one sphere per VALU instruction, 9 operations per test instead of 11:
-//   h = d.c - d.o  (3 fma, first one starting from -d.o),   s = 2 o.c - |o|^2 (3 fma, first one starting from -|o|^2),
-//   disc' = h^2 + (s + w),  w = r^2 - |c|^2 + slack  (1 add, 1 fma), compare.
-// |c|^2 - 2 o.c + |o|^2 cancels catastrophically, so this form only FILTERS: the slacks (2^-17 (|c|^2 + r^2) in w,
-// 2^-17 |o|^2 in the starting value) exceed its rounding error plus that of the exact test, so every sphere the
-// exact test accepts reaches on_candidate(position), where it is tested exactly.
-template <typename OnCandidate>
-__device__ __forceinline__ void scan_expanded(const float4* __restrict__ filter_geom, int32_t n_padded, const PathRay& ray,
-                                              OnCandidate&& on_candidate) {
+// Hybrid scan: an expanded-form filter in front of the exact test.
+//   h  = d.c - d.o                 3 fma, the first starting from -d.o
+//   q  = 2 o.c - |o|^2 (1 - 2^-17) 3 fma, the first starting from -|o|^2 (1 - 2^-17)
+//   listed  <=>  h^2 + q >= nw,    nw = |c|^2 - r^2 - 2^-17 (|c|^2 + r^2)          1 fma, 1 compare
+// |c|^2 - 2 o.c + |o|^2 cancels catastrophically, so this form only FILTERS: the two slacks exceed its rounding
+// error plus that of the exact test (46 eps ((|c|+|o|)^2 + r^2) against 128 eps (|c|^2 + |o|^2 + r^2), eps = 2^-24),
+// so every sphere the exact test would accept is listed, and listed spheres (about one test in 2 500 on the
+// 485-sphere scene) then take the exact test.  Results are therefore identical to scan_scalar's.
+// Operand sources: cx, cy of two spheres per wave-uniform ds_read_b128 (LDS, VGPR operands); cz and nw through
+// scalar loads (3 SGPR-sourced operations per test).
+__device__ __forceinline__ void scan_hybrid(const float4* lds_xy, const float4* __restrict__ filter_zn,
+                                            const float4* __restrict__ narrow_geom, int32_t n_padded, const PathRay& ray,
+                                            ScanBest& b) {
     const float dx = ray.d.x, dy = ray.d.y, dz = ray.d.z;
     const float ox2 = 2.f * ray.o.x, oy2 = 2.f * ray.o.y, oz2 = 2.f * ray.o.z;
     const float ndo = -dot(ray.d, ray.o);
     const float oo = dot(ray.o, ray.o);
-    const float noo = fmaf(oo, 7.62939453125e-6f, -oo);
+    const float noo = fmaf(oo, kSlack, -oo);
     for (int32_t k = 0; k < n_padded; k += kUnroll) {
-        float dv[kUnroll];
-#pragma unroll
-        for (int32_t u = 0; u < kUnroll; ++u) {
-            const float4 s = filter_geom[k + u]; // cx, cy, cz, w: scalar loads
-            const float h = fmaf(dz, s.z, fmaf(dy, s.y, fmaf(dx, s.x, ndo)));
-            const float q = fmaf(oz2, s.z, fmaf(oy2, s.y, fmaf(ox2, s.x, noo))) + s.w;
-            dv[u] = fmaf(h, h, q);
-        }
-#pragma unroll
-        for (int32_t u = 0; u < kUnroll; ++u)
-            if (dv[u] >= 0.f) on_candidate(k + u);
-    }
-}
-
-// The expanded-form filter with its sphere operands split between the two sources so that neither limits the
-// VALU: cx, cy come from LDS (wave-uniform ds_read_b128 = two spheres), cz and w through scalar loads.  An
-// SGPR-sourced operation costs ~3.6 cycles of the SIMD's scalar-operand path against 2.2 cycles of ALU time per
-// operation; with 3 of the 9 operations per test SGPR-sourced (10.8 cycles) the ALU (19.5 cycles) stays the bound,
-// and the LDS moves 8 bytes per test instead of 16.
-template <typename OnCandidate>
-__device__ __forceinline__ void scan_hybrid(const float4* lds_xy, const float4* __restrict__ filter_zw, int32_t n_padded,
-                                            const PathRay& ray, OnCandidate&& on_candidate) {
-    const float dx = ray.d.x, dy = ray.d.y, dz = ray.d.z;
-    const float ox2 = 2.f * ray.o.x, oy2 = 2.f * ray.o.y, oz2 = 2.f * ray.o.z;
-    const float ndo = -dot(ray.d, ray.o);
-    const float oo = dot(ray.o, ray.o);
-    const float noo = fmaf(oo, 7.62939453125e-6f, -oo);
-    for (int32_t k = 0; k < n_padded; k += kUnroll) {
-        float dv[kUnroll];
+        float lhs[kUnroll], rhs[kUnroll];
 #pragma unroll
         for (int32_t u = 0; u < kUnroll; u += 2) {
-            const float4 xy = lds_xy[(k + u) >> 1];        // cx0, cy0, cx1, cy1 (LDS broadcast)
-            const float4 zw = filter_zw[(k + u) >> 1];     // cz0, w0, cz1, w1 (scalar load)
-            const float h0 = fmaf(dz, zw.x, fmaf(dy, xy.y, fmaf(dx, xy.x, ndo)));
-            const float q0 = fmaf(oz2, zw.x, fmaf(oy2, xy.y, fmaf(ox2, xy.x, noo))) + zw.y;
-            dv[u] = fmaf(h0, h0, q0);
-            const float h1 = fmaf(dz, zw.z, fmaf(dy, xy.w, fmaf(dx, xy.z, ndo)));
-            const float q1 = fmaf(oz2, zw.z, fmaf(oy2, xy.w, fmaf(ox2, xy.z, noo))) + zw.w;
-            dv[u + 1] = fmaf(h1, h1, q1);
+            const float4 xy = lds_xy[(k + u) >> 1];    // cx0, cy0, cx1, cy1
+            const float4 zn = filter_zn[(k + u) >> 1]; // cz0, nw0, cz1, nw1
+            const float h0 = fmaf(dz, zn.x, fmaf(dy, xy.y, fmaf(dx, xy.x, ndo)));
+            const float q0 = fmaf(oz2, zn.x, fmaf(oy2, xy.y, fmaf(ox2, xy.x, noo)));
+            lhs[u] = fmaf(h0, h0, q0);
+            rhs[u] = zn.y;
+            const float h1 = fmaf(dz, zn.z, fmaf(dy, xy.w, fmaf(dx, xy.z, ndo)));
+            const float q1 = fmaf(oz2, zn.z, fmaf(oy2, xy.w, fmaf(ox2, xy.z, noo)));
+            lhs[u + 1] = fmaf(h1, h1, q1);
+            rhs[u + 1] = zn.w;
         }
 #pragma unroll
         for (int32_t u = 0; u < kUnroll; ++u)
-            if (dv[u] >= 0.f) on_candidate(k + u);
+            if (lhs[u] >= rhs[u]) exact_test(b, narrow_geom[k + u], ray, k + u);
     }
 }
 
-constexpr int kPoolItems = 64; // work items a wave takes from the global queue per atomic
-constexpr int kQueueCap = 16;
-constexpr int kTrStride = 9;  // floats per ray in the operand staging rows of the matrix-core scan (odd: no bank conflicts)
-typedef float f32x4 __attribute__((ext_vector_type(4))); // per-lane candidate slots in LDS (variants 2, 3)
-
-template <int VARIANT>
+template <bool HYBRID>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void render_f32_kernel(
-    CamDev<float> cam, const float4* __restrict__ narrow_geom, const float4* __restrict__ filter_geom,
-    const float4* __restrict__ filter_zw,
-    const v2f* __restrict__ narrow_pairs,
-    const int32_t* __restrict__ narrow_index, const float* __restrict__ narrow_tiles, int32_t n_tiles,
-    int32_t n_narrow_padded, const int32_t* __restrict__ wide_index, int32_t n_wide,
-    const double* __restrict__ geom64, const float4* __restrict__ geom32, const float4* __restrict__ mat32,
-    const uint32_t* __restrict__ kind, Partition part, RngKey key, int32_t samples_per_item, int32_t n_chunks,
-    unsigned long long n_items, unsigned long long* __restrict__ accum, DeviceCounters* counters) {
+    CamDev<float> cam, const float4* __restrict__ narrow_geom, const float4* __restrict__ filter_xy,
+    const float4* __restrict__ filter_zn, const int32_t* __restrict__ narrow_index,
+    const int32_t* __restrict__ wide_index, const double* __restrict__ geom64, const float4* __restrict__ geom32,
+    const float4* __restrict__ mat32, const uint32_t* __restrict__ kind, int32_t n_narrow_padded, int32_t n_wide,
+    Partition part, RngKey key, int32_t samples_per_item, int32_t n_chunks, unsigned long long n_items,
+    unsigned long long* __restrict__ accum, DeviceCounters* counters) {
+    // The tables come as separate __restrict__ pointers: with that the compiler knows the wave-uniform reads of
+    // the sphere tables cannot alias a store and emits scalar loads for them.
     const int lane = __lane_id();
-    const long long npix = (long long)part.n_rows * cam.W;
-    extern __shared__ float4 lds_geom[]; // VARIANT 7: the narrow-sphere table, staged once per block
-    if constexpr (VARIANT == 7) {
-        for (int32_t k = threadIdx.x; k < n_narrow_padded; k += blockDim.x) lds_geom[k] = narrow_geom[k];
-        __syncthreads();
-    }
-    if constexpr (VARIANT == 8) { // cx, cy of two consecutive spheres of the filter table per float4
-        for (int32_t k = threadIdx.x; k < n_narrow_padded / 2; k += blockDim.x) {
-            const float4 a = filter_geom[2 * k], b = filter_geom[2 * k + 1];
-            lds_geom[k] = make_float4(a.x, a.y, b.x, b.y);
-        }
-        __syncthreads();
+    const uint32_t npix = (uint32_t)part.n_rows * (uint32_t)cam.W;
+    extern __shared__ float4 lds_xy[]; // HYBRID: cx, cy of two consecutive narrow spheres per entry
+    if constexpr (HYBRID) {
+        for (int32_t k = threadIdx.x; k < n_narrow_padded / 2; k += blockDim.x) lds_xy[k] = filter_xy[k];
+        __syncthreads(); // the only block-wide wait: every wave passes here once, before any work is drawn
     }
 
     bool alive = false, done = false, have_item = false;
     int32_t s_next = 0, s_end = 0;
-    long long pix = 0;
+    uint32_t pix = 0;
     int32_t pi = 0, pj = 0;
     unsigned long long acc_r = 0, acc_g = 0, acc_b = 0;
     uint32_t n_seg = 0, n_samples = 0;
-
     unsigned long long pool_next = 0ull, pool_end = 0ull; // wave-uniform
 
     PathRay ray = {{0.f, 0.f, 0.f}, {0.f, 0.f, 1.f}, 0.001f};
@@ -314,10 +212,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     for (;;) {
         // ---- refill ---------------------------------------------------------------------------
         bool need_item = !alive && !done && s_next >= s_end;
-        if (need_item && have_item) {
-            atomicAdd(&accum[0 * npix + pix], acc_r);
-            atomicAdd(&accum[1 * npix + pix], acc_g);
-            atomicAdd(&accum[2 * npix + pix], acc_b);
+        if (need_item && have_item) { // colors.rs:38, order-free
+            atomicAdd(&accum[pix], acc_r);
+            atomicAdd(&accum[npix + pix], acc_g);
+            atomicAdd(&accum[2u * npix + pix], acc_b);
             have_item = false;
         }
         // Work items come from a wave-private pool [pool_next, pool_end) that one returning atomic on the
@@ -340,12 +238,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                 const unsigned long long item = pool_next + (unsigned long long)rank;
                 need_item = false;
                 if (item >= n_items) {
-                    done = true;
+                    done = true; // every lane reaches this once the queue is exhausted: the wave then drains and exits
                 } else {
-                    pix = (long long)(item / (unsigned long long)n_chunks);
+                    pix = (uint32_t)(item / (unsigned long long)n_chunks);
                     const int32_t chunk = (int32_t)(item - (unsigned long long)pix * (unsigned long long)n_chunks);
-                    const int32_t r = (int32_t)(pix / cam.W);
-                    pi = (int32_t)(pix - (long long)r * cam.W);
+                    const int32_t r = (int32_t)(pix / (uint32_t)cam.W);
+                    pi = (int32_t)(pix - (uint32_t)r * (uint32_t)cam.W);
                     pj = part.row_begin + r * part.row_step;
                     s_next = chunk * samples_per_item;
                     s_end = min(cam.spp, s_next + samples_per_item);
@@ -369,173 +267,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         }
         if (__ballot(alive) == 0ull) break;
 
-        [[maybe_unused]] uint32_t n_listed = 0;
-        [[maybe_unused]] const uint32_t* my_list = nullptr;
-        if constexpr (VARIANT == 5) {
-            // ---- matrix-core filter -------------------------------------------------------------------
-            // The line-sphere discriminant in expanded form is two rays x spheres products with K = 4:
-            //   H = [dx dy dz -d.o] . [cx cy cz 1]            Q = [2ox 2oy 2oz 1] . [cx cy cz w] + cinit
-            //   w = r^2 - |c|^2 + slack_c,  cinit = -|o|^2 + slack_o,   filter: H^2 + Q >= 0
-            // The expanded form cancels badly, so it only FILTERS: the slacks (2^-17 (|c|^2 + r^2) and
-            // 2^-17 |o|^2) exceed its rounding error plus that of the exact f32 test, hence every sphere the
-            // exact test would accept is listed, and listed spheres are then tested exactly as in the other
-            // variants.  16 rays x 16 spheres per v_mfma_f32_16x16x4_f32; the matrix pipe works beside the VALU.
-            __shared__ float tr[256 * kTrStride];
-            __shared__ uint32_t cand_cnt[256];
-            __shared__ uint32_t cand_list[kQueueCap * 256];
-            const int tid = threadIdx.x, wbase = tid & ~63;
-            {
-                float* row = tr + tid * kTrStride;
-                const float oo = dot(ray.o, ray.o);
-                row[0] = ray.d.x; row[1] = ray.d.y; row[2] = ray.d.z; row[3] = -dot(ray.d, ray.o);
-                row[4] = 2.f * ray.o.x; row[5] = 2.f * ray.o.y; row[6] = 2.f * ray.o.z; row[7] = 1.f;
-                row[8] = alive ? fmaf(oo, 7.62939453125e-6f, -oo) : -1e30f; // a dead lane's ray lists nothing
-                cand_cnt[tid] = 0u;
-            }
-            __builtin_amdgcn_wave_barrier(); // a wave's LDS operations complete in order; the waves are independent
-            const int r16 = lane & 15, kq = lane >> 4;
-            float aH[4], aQ[4];
-            f32x4 cin[4];
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const float* src = tr + (wbase + 16 * b + r16) * kTrStride; // A[row = lane&15][k = lane>>4]
-                aH[b] = src[kq];
-                aQ[b] = src[4 + kq];
-#pragma unroll
-                for (int g = 0; g < 4; ++g) cin[b][g] = tr[(wbase + 16 * b + 4 * kq + g) * kTrStride + 8]; // C row = 4*(lane>>4)+g
-            }
-            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-            float bq = narrow_tiles[lane]; // B[k = lane>>4][col = lane&15]: lanes 0-15 cx, 16-31 cy, 32-47 cz, 48-63 w
-            for (int32_t t = 0; t < n_tiles; ++t) {
-                const float bq_next = narrow_tiles[(size_t)(t + 1) * 64 + lane]; // the table ends with a spare tile
-                const float bh = kq == 3 ? 1.f : bq;
-                f32x4 d[4];
-                float m = -INFINITY;
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    const f32x4 hh = __builtin_amdgcn_mfma_f32_16x16x4f32(aH[b], bh, zero, 0, 0, 0);
-                    const f32x4 qq = __builtin_amdgcn_mfma_f32_16x16x4f32(aQ[b], bq, cin[b], 0, 0, 0);
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        d[b][g] = fmaf(hh[g], hh[g], qq[g]);
-                        m = fmaxf(m, d[b][g]);
-                    }
-                }
-                if (__ballot(m >= 0.f) != 0ull) { // rare: some ray of the wave may meet some sphere of the tile
-#pragma unroll
-                    for (int b = 0; b < 4; ++b)
-#pragma unroll
-                        for (int g = 0; g < 4; ++g)
-                            if (d[b][g] >= 0.f) {
-                                const int slot = wbase + 16 * b + 4 * kq + g; // the ray's lane
-                                const uint32_t n = atomicAdd(&cand_cnt[slot], 1u);
-                                if (n < (uint32_t)kQueueCap) cand_list[n * 256 + slot] = (uint32_t)(t * 16 + r16);
-                            }
-                }
-                bq = bq_next;
-            }
-            __builtin_amdgcn_wave_barrier();
-            n_listed = cand_cnt[tid];
-            my_list = cand_list + tid;
-        }
-
         if (alive) {
             // ---- closest hit over the sphere list: hittable_list.rs:60-74 -----------------------
             n_seg++;
             const float ox = ray.o.x, oy = ray.o.y, oz = ray.o.z, dx = ray.d.x, dy = ray.d.y, dz = ray.d.z;
             const float tmin = ray.tmin;
             ScanBest sb = {INFINITY, -1, false};
-            if constexpr (VARIANT == 0 || VARIANT == 1 || VARIANT == 4 || VARIANT == 7) {
-                // roots evaluated where the candidate is found
-                auto accept = [&](float h, float disc, int32_t pos) { scan_accept(sb, h, disc, tmin, pos); };
-                if constexpr (VARIANT == 1)
-                    scan_packed(narrow_pairs, n_narrow_padded, ray, accept);
-                else if constexpr (VARIANT == 7)
-                    scan_lds(lds_geom, n_narrow_padded, ray, accept);
-                else
-                    scan_plain<VARIANT == 4>(narrow_geom, n_narrow_padded, ray, accept);
-            } else if constexpr (VARIANT == 8) {
-                auto exact = [&](int32_t pos) {
-                    const float4 s = narrow_geom[pos];
-                    const float ocx = s.x - ox, ocy = s.y - oy, ocz = s.z - oz;
-                    const float h = fmaf(ocz, dz, fmaf(ocy, dy, ocx * dx));
-                    const float qq = fmaf(-ocz, ocz, fmaf(-ocy, ocy, fmaf(-ocx, ocx, s.w)));
-                    const float disc = fmaf(h, h, qq);
-                    if (disc >= 0.f) scan_accept(sb, h, disc, tmin, pos);
-                };
-                scan_hybrid(lds_geom, filter_zw, n_narrow_padded, ray, exact);
-            } else if constexpr (VARIANT == 6) {
-                auto exact = [&](int32_t pos) { // the test of the other variants, on the spheres the filter lets through
-                    const float4 s = narrow_geom[pos];
-                    const float ocx = s.x - ox, ocy = s.y - oy, ocz = s.z - oz;
-                    const float h = fmaf(ocz, dz, fmaf(ocy, dy, ocx * dx));
-                    const float qq = fmaf(-ocz, ocz, fmaf(-ocy, ocy, fmaf(-ocx, ocx, s.w)));
-                    const float disc = fmaf(h, h, qq);
-                    if (disc >= 0.f) scan_accept(sb, h, disc, tmin, pos);
-                };
-                scan_expanded(filter_geom, n_narrow_padded, ray, exact);
-            } else if constexpr (VARIANT == 5) {
-                auto exact = [&](int32_t pos) {
-                    const float4 s = narrow_geom[pos];
-                    const float ocx = s.x - ox, ocy = s.y - oy, ocz = s.z - oz;
-                    const float h = fmaf(ocz, dz, fmaf(ocy, dy, ocx * dx));
-                    const float qq = fmaf(-ocz, ocz, fmaf(-ocy, ocy, fmaf(-ocx, ocx, s.w)));
-                    const float disc = fmaf(h, h, qq);
-                    if (disc >= 0.f) scan_accept<true>(sb, h, disc, tmin, pos);
-                };
-                const bool overflow = n_listed > (uint32_t)kQueueCap;
-                if (overflow) { // more candidates than list slots: this ray scans every sphere exactly
-                    auto accept = [&](float h, float disc, int32_t pos) { scan_accept(sb, h, disc, tmin, pos); };
-                    scan_plain<false>(narrow_geom, n_narrow_padded, ray, accept);
-                }
-                const uint32_t n_mine = overflow ? 0u : n_listed;
-                for (uint32_t q = 0; __ballot(q < n_mine) != 0ull; ++q)
-                    if (q < n_mine) exact((int32_t)my_list[q * 256]);
-            } else {
-                // candidates are only recorded during the scan (one LDS store each) and their roots are
-                // evaluated afterwards, each lane walking its own short list; slot s of a lane is word
-                // s*256 + tid, which is conflict-free for any mix of per-lane fill levels
-                __shared__ uint32_t queue[kQueueCap * 256];
-                uint32_t* const my_queue = queue + threadIdx.x;
-                int32_t n_queued = 0;
-                auto push = [&](float h, float disc, int32_t pos) {
-                    if (n_queued < kQueueCap) {
-                        my_queue[n_queued * 256] = (uint32_t)pos;
-                        n_queued++;
-                    } else {
-                        scan_accept(sb, h, disc, tmin, pos); // list full: evaluate in place
-                    }
-                };
-                if constexpr (VARIANT == 3)
-                    scan_packed(narrow_pairs, n_narrow_padded, ray, push);
-                else
-                    scan_plain<false>(narrow_geom, n_narrow_padded, ray, push);
-                for (int32_t q = 0; __ballot(q < n_queued) != 0ull; ++q) {
-                    if (q < n_queued) {
-                        const int32_t pos = (int32_t)my_queue[q * 256];
-                        const float4 s = narrow_geom[pos];
-                        const float ocx = s.x - ox, ocy = s.y - oy, ocz = s.z - oz;
-                        const float h = fmaf(ocz, dz, fmaf(ocy, dy, ocx * dx));
-                        const float qq = fmaf(-ocz, ocz, fmaf(-ocy, ocy, fmaf(-ocx, ocx, s.w)));
-                        scan_accept(sb, h, fmaf(h, h, qq), tmin, pos);
-                    }
-                }
-            }
+            if constexpr (HYBRID)
+                scan_hybrid(lds_xy, filter_zn, narrow_geom, n_narrow_padded, ray, sb);
+            else
+                scan_scalar(narrow_geom, n_narrow_padded, ray, sb);
             float best = sb.t;
-            const int32_t bpos = sb.pos;
-            const bool bfar = sb.far;
             // Re-evaluate the winner from the perpendicular remainder |oc - h d|, which does not cancel.
             int32_t bidx = -1; // position in the caller's list
             F3 hp = {0.f, 0.f, 0.f}, hn = {0.f, 0.f, 0.f};
-            if (bpos >= 0) {
-                bidx = narrow_index[bpos];
+            if (sb.pos >= 0) {
+                bidx = narrow_index[sb.pos];
                 const float4 s = geom32[bidx];
                 const F3 oc = {s.x - ox, s.y - oy, s.z - oz};
                 const float h = dot(oc, ray.d);
                 const F3 l = {fmaf(-h, dx, oc.x), fmaf(-h, dy, oc.y), fmaf(-h, dz, oc.z)};
                 const float disc = fmaxf(fmaf(s.w, s.w, -dot(l, l)), 0.f);
                 const float sq = fsqrt(disc);
-                best = bfar ? h + sq : h - sq;
+                best = sb.far ? h + sq : h - sq;
                 hp = {fmaf(best, dx, ox), fmaf(best, dy, oy), fmaf(best, dz, oz)};
                 const float ir = rcp(s.w);
                 hn = {(hp.x - s.x) * ir, (hp.y - s.y) * ir, (hp.z - s.z) * ir}; // sphere.rs:52
@@ -679,25 +433,17 @@ __global__ __launch_bounds__(256) void resolve_f32_kernel(int32_t W, int32_t spp
 F32Plan plan_render_f32(const CamDev<float>& cam, const Partition& part, int32_t samples_per_item, int32_t variant,
                         int32_t n_narrow_padded, int device) {
     F32Plan plan{};
-    plan.variant = variant;
-    plan.lds_bytes = variant == 7 ? (size_t)n_narrow_padded * 16u : variant == 8 ? (size_t)n_narrow_padded * 8u : 0u;
     plan.block = 256;
+    const size_t table_bytes = (size_t)n_narrow_padded * 8u; // cx, cy per sphere
+    plan.hybrid = variant == DRAY_SCAN_SCALAR ? 0 : (table_bytes <= kHybridLdsLimit ? 1 : 0);
+    plan.lds_bytes = plan.hybrid ? table_bytes : 0u;
     int cus = 256, per_cu = 4;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
     int occ = 0;
-    hipError_t oe = hipErrorUnknown;
-    switch (variant) {
-    case 1: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, render_f32_kernel<1>, plan.block, 0); break;
-    case 2: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, render_f32_kernel<2>, plan.block, 0); break;
-    case 3: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, render_f32_kernel<3>, plan.block, 0); break;
-    case 4: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, render_f32_kernel<4>, plan.block, 0); break;
-    case 5: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, render_f32_kernel<5>, plan.block, 0); break;
-    case 6: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, render_f32_kernel<6>, plan.block, 0); break;
-    case 7: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, render_f32_kernel<7>, plan.block, plan.lds_bytes); break;
-    case 8: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, render_f32_kernel<8>, plan.block, plan.lds_bytes); break;
-    default: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, render_f32_kernel<0>, plan.block, 0); break;
-    }
+    const hipError_t oe =
+        plan.hybrid ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, render_f32_kernel<true>, plan.block, plan.lds_bytes)
+                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, render_f32_kernel<false>, plan.block, 0);
     if (oe == hipSuccess && occ > 0) per_cu = occ;
     plan.grid = cus * per_cu;
     const long long npix = (long long)part.n_rows * cam.W;
@@ -724,22 +470,19 @@ hipError_t launch_render_f32(const CamDev<float>& cam, const SceneDev& scene, co
                              hipStream_t stream) {
     const long long npix = (long long)part.n_rows * cam.W;
     if (npix <= 0 || cam.spp <= 0) return hipSuccess;
+    if (npix > 0x7fffffffLL / 3) return hipErrorInvalidValue; // the kernel indexes the three sum planes with 32 bits
     const unsigned long long n_items = (unsigned long long)npix * (unsigned long long)plan.n_chunks;
-    auto kern = render_f32_kernel<0>;
-    if (plan.variant == 1) kern = render_f32_kernel<1>;
-    if (plan.variant == 2) kern = render_f32_kernel<2>;
-    if (plan.variant == 3) kern = render_f32_kernel<3>;
-    if (plan.variant == 4) kern = render_f32_kernel<4>;
-    if (plan.variant == 5) kern = render_f32_kernel<5>;
-    if (plan.variant == 6) kern = render_f32_kernel<6>;
-    if (plan.variant == 7) kern = render_f32_kernel<7>;
-    if (plan.variant == 8) kern = render_f32_kernel<8>;
-    hipLaunchKernelGGL(kern, dim3(plan.grid), dim3(plan.block), plan.lds_bytes, stream, cam, (const float4*)scene.narrow_geom,
-                       (const float4*)scene.filter_geom, (const float4*)scene.filter_zw,
-                       (const v2f*)scene.narrow_pairs, scene.narrow_index, scene.narrow_tiles, scene.n_tiles,
-                       scene.n_narrow_padded, scene.wide_index,
-                       scene.n_wide, scene.geom64, (const float4*)scene.geom32, (const float4*)scene.mat32, scene.kind,
-                       part, key, plan.samples_per_item, plan.n_chunks, n_items, d_accum, d_counters);
+    const F32Tables& t = scene.f32;
+    if (plan.hybrid)
+        hipLaunchKernelGGL(render_f32_kernel<true>, dim3(plan.grid), dim3(plan.block), plan.lds_bytes, stream, cam,
+                           t.narrow_geom, t.filter_xy, t.filter_zn, t.narrow_index, t.wide_index, t.geom64, t.geom32,
+                           t.mat32, t.kind, t.n_narrow_padded, t.n_wide, part, key, plan.samples_per_item, plan.n_chunks,
+                           n_items, d_accum, d_counters);
+    else
+        hipLaunchKernelGGL(render_f32_kernel<false>, dim3(plan.grid), dim3(plan.block), 0, stream, cam, t.narrow_geom,
+                           t.filter_xy, t.filter_zn, t.narrow_index, t.wide_index, t.geom64, t.geom32, t.mat32, t.kind,
+                           t.n_narrow_padded, t.n_wide, part, key, plan.samples_per_item, plan.n_chunks, n_items,
+                           d_accum, d_counters);
     return hipGetLastError();
 }
 

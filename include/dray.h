@@ -102,6 +102,13 @@ enum {
     DRAY_FLAG_COMPACT_ROWS = 2u
 };
 
+/* Sphere-scan formulations of the f32 kernel; all give identical images. */
+enum {
+    DRAY_SCAN_AUTO = 0,   /* hybrid when the sphere table fits in LDS (<= 8192 narrow spheres), else scalar */
+    DRAY_SCAN_SCALAR = 1, /* exact test on every sphere, geometry through scalar loads */
+    DRAY_SCAN_HYBRID = 2  /* expanded-form filter (geometry from LDS + scalar loads) in front of the exact test */
+};
+
 typedef struct dray_opts {
     uint64_t seed;
     uint32_t mode;
@@ -112,7 +119,7 @@ typedef struct dray_opts {
     int32_t row_begin;        /* scanline partition: rows row_begin, row_begin+row_step, ... */
     int32_t row_step;         /* 0 is read as 1 */
     int32_t samples_per_item; /* f32 mode: samples per work item, 0 = library default */
-    int32_t variant;          /* f32 mode: scan formulation, 0 = library default; others are A/B builds */
+    int32_t variant;          /* f32 mode: sphere-scan formulation, a DRAY_SCAN_* value */
 } dray_opts;
 
 typedef struct dray_stats {

@@ -172,15 +172,26 @@ def test_f32_item_size_invariance(dray, gpu):
 
 
 def test_f32_scan_variants_agree(dray, gpu):
-    """The packed-f32 scan performs the same operations on the same operands as the one-sphere-per-instruction
-    scan, two spheres at a time: images, sums and segment counts are identical."""
-    spheres = dray.scene_final(1)
+    """The hybrid scan only filters in front of the same exact test the scalar scan applies to every sphere:
+    images, sums and segment counts are identical."""
     cam = dray.camera_final(width=96, spp=12, depth=50)
     cam.mode = dray.MODE_F32
-    a = render_gpu(dray, gpu, spheres, cam, seed=13, variant=0)
-    for v in (1, 2, 3, 4, 5, 6, 7, 8):
-        b = render_gpu(dray, gpu, spheres, cam, seed=13, variant=v)
-        assert (a[0] == b[0]).all() and (a[1] == b[1]).all() and a[3].segments == b[3].segments, v
+    for spheres in (dray.scene_final(1), dray.scene_final(7), dray.scene_three_spheres()):
+        a = render_gpu(dray, gpu, spheres, cam, seed=13, variant=dray.SCAN_SCALAR)
+        for v in (dray.SCAN_HYBRID, dray.SCAN_AUTO):
+            b = render_gpu(dray, gpu, spheres, cam, seed=13, variant=v)
+            assert (a[0] == b[0]).all() and (a[1] == b[1]).all() and a[3].segments == b[3].segments, v
+    # a camera far from the origin: large |o| stresses the filter's slack (its error grows with |o|^2 + |c|^2)
+    far = dray.camera_final(width=96, spp=12, depth=50)
+    far.mode = dray.MODE_F32
+    far.lookfrom, far.lookat, far.vfov = (130.0, 20.0, 30.0), (0.0, 0.0, 0.0), 2.0
+    far.focus_dist, far.defocus_angle = 100.0, 0.0
+    spheres = dray.scene_final(1)
+    a = render_gpu(dray, gpu, spheres, far, seed=5, variant=dray.SCAN_SCALAR)
+    b = render_gpu(dray, gpu, spheres, far, seed=5, variant=dray.SCAN_HYBRID)
+    assert (a[0] == b[0]).all() and (a[1] == b[1]).all() and a[3].segments == b[3].segments
+    with pytest.raises(dray.DrayError):
+        render_gpu(dray, gpu, spheres, cam, seed=13, variant=9)
 
 
 def test_f32_close_to_oracle(dray, gpu, oracle):
