@@ -37,6 +37,11 @@ constexpr int kUnroll = 8;                    // spheres per scan block (the tab
 constexpr int kPoolItems = 64;                // work items a wave takes from the global queue per atomic
 constexpr float kSlack = 7.62939453125e-6f;   // 2^-17, see scan_hybrid
 
+// Waves per SIMD the register allocation of the trace kernel aims at (7 = at most 72 VGPRs; measured fastest: 6 -> 100.6 ms, 7 -> 96.4 ms, 8 -> 102.6 ms per 1200x675x500 frame).
+#ifndef DRAY_WAVES_PER_EU
+#define DRAY_WAVES_PER_EU 7
+#endif
+
 struct F3 {
     float x, y, z;
 };
@@ -49,10 +54,10 @@ __device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x);
 __device__ __forceinline__ float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 
 // vec3.rs:76-84: rejection sampling in the cube; attempt a = words 0..2 of block a of the stage.
-__device__ __forceinline__ F3 random_unit_vector(const Stream& st) {
+// `w` holds block 0 on entry (the caller computes it once for every kind of scatter).
+__device__ __forceinline__ F3 random_unit_vector(const Stream& st, uint32_t (&w)[4]) {
     for (uint32_t a = 0;; ++a) {
-        uint32_t w[4];
-        st.block(a, w);
+        if (a > 0) st.block(a, w);
         F3 p = {fmaf(2.f, u01<float>(w[0]), -1.f), fmaf(2.f, u01<float>(w[1]), -1.f), fmaf(2.f, u01<float>(w[2]), -1.f)};
         const float l2 = dot(p, p);
         if (1e-30f <= l2 && l2 <= 1.f) return p * rsq(l2);
@@ -179,7 +184,7 @@ __device__ __forceinline__ void scan_hybrid(const float4* lds_xy, const float4* 
 }
 
 template <bool HYBRID>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void render_f32_kernel(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DRAY_WAVES_PER_EU, DRAY_WAVES_PER_EU))) void render_f32_kernel(
     CamDev<float> cam, const float4* __restrict__ narrow_geom, const float4* __restrict__ filter_xy,
     const float4* __restrict__ filter_zn, const int32_t* __restrict__ narrow_index,
     const int32_t* __restrict__ wide_index, const double* __restrict__ geom64, const float4* __restrict__ geom32,
@@ -339,17 +344,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                 const bool front = dot(ray.d, hn) < 0.f; // hittable.rs:16-22
                 const F3 n = front ? hn : F3{-hn.x, -hn.y, -hn.z};
                 st.stage = (uint32_t)stage;
+                // Every scatter that draws at all starts with block 0 of the stage (Lambertian and Metal: first
+                // unit-vector attempt; Dialectric: the reflect/refract uniform), so it is computed once for all
+                // lanes of the wave, and the unit-vector rejection loop runs once for both materials: under
+                // divergence each separate loop would cost the maximum attempt count over its own lanes.
+                uint32_t w[4];
+                const bool wants_vector = mk == DRAY_MAT_LAMBERTIAN || mk == DRAY_MAT_METAL;
+                if (wants_vector || mk == DRAY_MAT_DIELECTRIC) st.block(0, w);
+                F3 ruv = {0.f, 0.f, 0.f};
+                if (wants_vector) ruv = random_unit_vector(st, w); // drawn even when a metal's fuzz is 0 (material.rs:75)
                 F3 nd = {0.f, 0.f, 0.f};
                 bool scattered = false;
                 if (mk == DRAY_MAT_LAMBERTIAN) { // material.rs:46-56
-                    nd = n + random_unit_vector(st);
+                    nd = n + ruv;
                     if (fabsf(nd.x) < 1e-8f && fabsf(nd.y) < 1e-8f && fabsf(nd.z) < 1e-8f) nd = n;
                     thr = {thr.x * m.x, thr.y * m.y, thr.z * m.z};
                     scattered = true;
                 } else if (mk == DRAY_MAT_METAL) { // material.rs:73-80; reflect(d, n) is already unit
                     const float dn = dot(ray.d, n);
                     const F3 refl = {fmaf(-2.f * dn, n.x, dx), fmaf(-2.f * dn, n.y, dy), fmaf(-2.f * dn, n.z, dz)};
-                    const F3 ruv = random_unit_vector(st);
                     nd = {fmaf(m.w, ruv.x, refl.x), fmaf(m.w, ruv.y, refl.y), fmaf(m.w, ruv.z, refl.z)};
                     thr = {thr.x * m.x, thr.y * m.y, thr.z * m.z};
                     scattered = dot(nd, n) > 0.f;
@@ -358,9 +371,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                     const float cos_theta = fminf(-dot(ray.d, n), 1.0f);
                     const float sin_theta = fsqrt(fmaxf(fmaf(-cos_theta, cos_theta, 1.0f), 0.f));
                     bool reflects = ri * sin_theta > 1.0f;
-                    if (!reflects) {
-                        uint32_t w[4];
-                        st.block(0, w);
+                    if (!reflects) { // the uniform counts only when refraction is possible (material.rs:114)
                         float r0 = (1.f - ri) * rcp(1.f + ri);
                         r0 = r0 * r0;
                         const float x = 1.f - cos_theta, x2 = x * x;
