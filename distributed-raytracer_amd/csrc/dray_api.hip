@@ -297,6 +297,7 @@ int render_device_impl(const dray_camera* cam, dray_scene* scene, uint32_t* d_co
     if (opts.mode == DRAY_MODE_F32) {
         const CamDev<float> c = make_cam<float>(*cam, dv);
         const F32Plan plan = plan_render_f32(c, part, opts.samples_per_item, opts.variant, scene->dev.n_narrow_padded, scene->device);
+        if (opts.variant == DRAY_SCAN_HYBRID && !plan.hybrid) return DRAY_ERR_UNSUPPORTED; // table beyond the LDS staging limit
         if (plan.accum_words > scene->accum_capacity) {
             if (scene->d_accum) HIP_TRY(hipFree(scene->d_accum));
             scene->d_accum = nullptr;
@@ -526,28 +527,30 @@ int dray_scene_three_spheres(dray_sphere* out, size_t cap) {
     return 4;
 }
 
-int dray_scene_final(uint64_t seed, dray_sphere* out, size_t cap) { // main.rs:13-50
+int dray_scene_recipe(uint64_t seed, int32_t lo, int32_t hi, double p_diffuse, double p_metal, double fuzz_max,
+                      dray_sphere* out, size_t cap) { // main.rs:13-50, generalised
     if (!out || cap < 1) return DRAY_ERR_BUFFER_TOO_SMALL;
+    if (hi < lo) return DRAY_ERR_INVALID_ARG;
     SceneStream rs;
     rs.key[0] = (uint32_t)seed;
     rs.key[1] = (uint32_t)(seed >> 32);
     size_t n = 0;
     put_sphere(&out[n++], 0., -1000., 0., 1000., DRAY_MAT_LAMBERTIAN, 0.5, 0.5, 0.5, 0.);
-    for (int a = -11; a < 11; ++a)
-        for (int b = -11; b < 11; ++b) {
+    for (int a = lo; a < hi; ++a)
+        for (int b = lo; b < hi; ++b) {
             const double choose_mat = rs.next();
             const double cx = (double)a + 0.9 * rs.next();
             const double cz = (double)b + 0.9 * rs.next();
             const D3 dlt = sub(D3{cx, 0.2, cz}, D3{4., 0.2, 0.});
             if (std::sqrt(dot(dlt, dlt)) > 0.9) {
                 if (n >= cap) return DRAY_ERR_BUFFER_TOO_SMALL;
-                if (choose_mat < 0.8) {
+                if (choose_mat < p_diffuse) {
                     const double r0 = rs.next(), r1 = rs.next(), r2 = rs.next();
                     const double s0 = rs.next(), s1 = rs.next(), s2 = rs.next();
                     put_sphere(&out[n++], cx, 0.2, cz, 0.2, DRAY_MAT_LAMBERTIAN, r0 * s0, r1 * s1, r2 * s2, 0.);
-                } else if (choose_mat < 0.95) {
+                } else if (choose_mat < p_diffuse + p_metal) {
                     const double a0 = rs.range(0.5, 1.), a1 = rs.range(0.5, 1.), a2 = rs.range(0.5, 1.);
-                    const double fuzz = rs.range(0., 0.5);
+                    const double fuzz = rs.range(0., fuzz_max);
                     put_sphere(&out[n++], cx, 0.2, cz, 0.2, DRAY_MAT_METAL, a0, a1, a2, fuzz);
                 } else {
                     put_sphere(&out[n++], cx, 0.2, cz, 0.2, DRAY_MAT_DIELECTRIC, 0., 0., 0., 1.5);
@@ -559,6 +562,10 @@ int dray_scene_final(uint64_t seed, dray_sphere* out, size_t cap) { // main.rs:1
     put_sphere(&out[n++], -4., 1., 0., 1.0, DRAY_MAT_LAMBERTIAN, 0.4, 0.2, 0.1, 0.);
     put_sphere(&out[n++], 4., 1., 0., 1.0, DRAY_MAT_METAL, 0.7, 0.6, 0.5, 0.0);
     return (int)n;
+}
+
+int dray_scene_final(uint64_t seed, dray_sphere* out, size_t cap) {
+    return dray_scene_recipe(seed, -11, 11, 0.8, 0.15, 0.5, out, cap);
 }
 
 } // extern "C"

@@ -226,6 +226,25 @@ def scene_final(seed=1):
     return arr[:n].copy()
 
 
+def scene_recipe(seed, lo, hi, p_diffuse, p_metal, fuzz_max):
+    """The recipe of main.rs:13-50 over cells [lo, hi)^2 with other material shares."""
+    arr = np.zeros((hi - lo) * (hi - lo) + 8, dtype=_ffi.SPHERE_DTYPE)
+    n = _ffi.lib().dray_scene_recipe(seed, lo, hi, p_diffuse, p_metal, fuzz_max, arr.ctypes.data, len(arr))
+    if n < 0:
+        _ffi.check(n)
+    return arr[:n].copy()
+
+
+def scene_grid_10k(seed=1):
+    """About 10 000 small spheres on a 100 x 100 grid with the reference scene's density and material mix."""
+    return scene_recipe(seed, -50, 50, 0.8, 0.15, 0.5)
+
+
+def scene_glass_metal(seed=1):
+    """The reference scene's layout with half glass and half low-fuzz metal: long specular paths."""
+    return scene_recipe(seed, -11, 11, 0.0, 0.5, 0.1)
+
+
 def scene_three_spheres():
     arr = np.zeros(4, dtype=_ffi.SPHERE_DTYPE)
     n = _ffi.lib().dray_scene_three_spheres(arr.ctypes.data, len(arr))

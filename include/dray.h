@@ -106,7 +106,8 @@ enum {
 enum {
     DRAY_SCAN_AUTO = 0,   /* hybrid when the sphere table fits in LDS (<= 8192 narrow spheres), else scalar */
     DRAY_SCAN_SCALAR = 1, /* exact test on every sphere, geometry through scalar loads */
-    DRAY_SCAN_HYBRID = 2  /* expanded-form filter (geometry from LDS + scalar loads) in front of the exact test */
+    DRAY_SCAN_HYBRID = 2  /* expanded-form filter (geometry from LDS + scalar loads) in front of the exact test;
+                             DRAY_ERR_UNSUPPORTED when the sphere table does not fit in LDS */
 };
 
 typedef struct dray_opts {
@@ -175,6 +176,10 @@ int dray_render_device(const dray_camera* cam, dray_scene* scene, uint32_t* d_co
  * Philox stream (pixel = sample = stage = 0xFFFFFFFF) of `seed`.  Returns the sphere count or a
  * negative dray_status (cap too small). */
 int dray_scene_final(uint64_t seed, dray_sphere* out, size_t cap);
+/* The same recipe over cells a, b in [lo, hi) with other material shares: a cell is diffuse below p_diffuse, metal
+ * (fuzz in [0, fuzz_max)) below p_diffuse + p_metal, glass otherwise.  dray_scene_final = (-11, 11, 0.8, 0.15, 0.5). */
+int dray_scene_recipe(uint64_t seed, int32_t lo, int32_t hi, double p_diffuse, double p_metal, double fuzz_max,
+                      dray_sphere* out, size_t cap);
 /* Ground + Lambertian + Dialectric + Metal test scene (4 spheres). */
 int dray_scene_three_spheres(dray_sphere* out, size_t cap);
 

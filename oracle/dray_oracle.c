@@ -571,8 +571,11 @@ int orc_scene_three_spheres(orc_sphere* out, size_t cap) {
     return 4;
 }
 
-/* main.rs:13-50 with the uniforms taken from one Philox stream (pixel = sample = stage = 0xFFFFFFFF). */
-int orc_scene_final(uint64_t seed, orc_sphere* out, size_t cap) {
+/* main.rs:13-50 with the uniforms taken from one Philox stream (pixel = sample = stage = 0xFFFFFFFF), generalised:
+ * cells a, b in [lo, hi), material thresholds p_diffuse and p_diffuse + p_metal, metal fuzz in [0, fuzz_max).
+ * The reference's scene is lo = -11, hi = 11, 0.8, 0.15, 0.5. */
+int orc_scene_recipe(uint64_t seed, int32_t lo, int32_t hi, double p_diffuse, double p_metal, double fuzz_max,
+                     orc_sphere* out, size_t cap) {
     orc_rng rng;
     memset(&rng, 0, sizeof rng);
     rng.key[0] = (uint32_t)seed;
@@ -582,8 +585,8 @@ int orc_scene_final(uint64_t seed, orc_sphere* out, size_t cap) {
     size_t n = 0;
     if (cap < 1) return -1;
     set_sphere(&out[n++], 0., -1000., 0., 1000., ORC_MAT_LAMBERTIAN, 0.5, 0.5, 0.5, 0.);
-    for (int a = -11; a < 11; ++a)
-        for (int b = -11; b < 11; ++b) {
+    for (int a = lo; a < hi; ++a)
+        for (int b = lo; b < hi; ++b) {
             double choose_mat = orc_rng_draw(&rng, k++);
             double cx = (double)a + 0.9 * orc_rng_draw(&rng, k++);
             double cz = (double)b + 0.9 * orc_rng_draw(&rng, k++);
@@ -591,16 +594,16 @@ int orc_scene_final(uint64_t seed, orc_sphere* out, size_t cap) {
             orc_v_sub(c, ref, dlt);
             if (orc_v_length(dlt) > 0.9) {
                 if (n >= cap) return -1;
-                if (choose_mat < 0.8) {
+                if (choose_mat < p_diffuse) {
                     double r1[3], r2[3], al[3];
                     for (int q = 0; q < 3; ++q) r1[q] = orc_rng_draw(&rng, k++);
                     for (int q = 0; q < 3; ++q) r2[q] = orc_rng_draw(&rng, k++);
                     orc_v_mul(r1, r2, al);
                     set_sphere(&out[n++], cx, 0.2, cz, 0.2, ORC_MAT_LAMBERTIAN, al[0], al[1], al[2], 0.);
-                } else if (choose_mat < 0.95) {
+                } else if (choose_mat < p_diffuse + p_metal) {
                     double al[3];
                     for (int q = 0; q < 3; ++q) al[q] = rng_range(&rng, k++, 0.5, 1.);
-                    double fuzz = rng_range(&rng, k++, 0., 0.5);
+                    double fuzz = rng_range(&rng, k++, 0., fuzz_max);
                     set_sphere(&out[n++], cx, 0.2, cz, 0.2, ORC_MAT_METAL, al[0], al[1], al[2], fuzz);
                 } else {
                     set_sphere(&out[n++], cx, 0.2, cz, 0.2, ORC_MAT_DIELECTRIC, 0., 0., 0., 1.5);
@@ -612,4 +615,8 @@ int orc_scene_final(uint64_t seed, orc_sphere* out, size_t cap) {
     set_sphere(&out[n++], -4., 1., 0., 1.0, ORC_MAT_LAMBERTIAN, 0.4, 0.2, 0.1, 0.);
     set_sphere(&out[n++], 4., 1., 0., 1.0, ORC_MAT_METAL, 0.7, 0.6, 0.5, 0.0);
     return (int)n;
+}
+
+int orc_scene_final(uint64_t seed, orc_sphere* out, size_t cap) {
+    return orc_scene_recipe(seed, -11, 11, 0.8, 0.15, 0.5, out, cap);
 }

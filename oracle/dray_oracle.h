@@ -166,6 +166,9 @@ int orc_render(const orc_camera* cam, const orc_sphere* s, size_t n, uint32_t* c
 /* Scene recipes.  final: src/main.rs:13-50 with a seeded stream; returns the sphere count (<= cap) or -1. */
 int orc_scene_three_spheres(orc_sphere* out, size_t cap);
 int orc_scene_final(uint64_t seed, orc_sphere* out, size_t cap);
+/* The same recipe over cells a, b in [lo, hi) with other material shares (final = -11, 11, 0.8, 0.15, 0.5). */
+int orc_scene_recipe(uint64_t seed, int32_t lo, int32_t hi, double p_diffuse, double p_metal, double fuzz_max,
+                     orc_sphere* out, size_t cap);
 
 #ifdef __cplusplus
 }

@@ -159,6 +159,8 @@ def lib():
                              C.c_uint64, C.c_uint32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, P(Stats)]
     L.orc_scene_three_spheres.argtypes = [P(Sphere), C.c_size_t]
     L.orc_scene_final.argtypes = [C.c_uint64, P(Sphere), C.c_size_t]
+    L.orc_scene_recipe.argtypes = [C.c_uint64, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double, P(Sphere),
+                                   C.c_size_t]
     _lib = L
     return L
 
@@ -233,6 +235,14 @@ def scene_three_spheres():
 def scene_final(seed):
     arr = (Sphere * 600)()
     n = lib().orc_scene_final(seed, arr, 600)
+    assert n > 0
+    return spheres_to_numpy(arr, n)
+
+
+def scene_recipe(seed, lo, hi, p_diffuse, p_metal, fuzz_max):
+    cap = (hi - lo) * (hi - lo) + 8
+    arr = (Sphere * cap)()
+    n = lib().orc_scene_recipe(seed, lo, hi, p_diffuse, p_metal, fuzz_max, arr, cap)
     assert n > 0
     return spheres_to_numpy(arr, n)
 

@@ -326,3 +326,106 @@ def test_edge_cases(dray, gpu, oracle):
     camz = dray.camera_three_spheres(width=32, spp=0, depth=5)
     col, raw, cnt, st = render_gpu(dray, gpu, dray.scene_three_spheres(), camz, seed=1)
     assert (col == 0).all() and (cnt == 0).all()
+
+
+def test_large_scene_scalar_fallback_and_hybrid(dray, gpu, oracle):
+    """A 10 001-sphere grid: f64 kernel equal to the oracle; the f32 kernel's automatic choice (the narrow
+    spheres exceed the hybrid scan's staging limit, so the scalar scan runs) equal to the forced scalar scan and
+    within the f32 bound of the oracle.  A 5 000-sphere grid still takes the hybrid scan and equals the scalar."""
+    spheres = dray.scene_grid_10k(2)
+    assert len(spheres) > 8192 + 4
+    cam = dray.camera_final(width=64, spp=2, depth=10)
+    cam.lookfrom, cam.focus_dist = (13.0, 6.0, 3.0), 14.0
+    ocol, oraw, ocnt, ost = oracle.render(ocam_from(oracle, cam), spheres, seed=17, threads=8)
+    cam.mode = dray.MODE_F64
+    col, raw, cnt, st = render_gpu(dray, gpu, spheres, cam, seed=17)
+    assert st.segments == ost.segments and st.n_spheres == len(spheres)
+    assert (raw == oraw).all() and lsb_diff(col, ocol).max() <= 1
+    cam.mode = dray.MODE_F32
+    a = render_gpu(dray, gpu, spheres, cam, seed=17, variant=dray.SCAN_AUTO)
+    b = render_gpu(dray, gpu, spheres, cam, seed=17, variant=dray.SCAN_SCALAR)
+    assert (a[0] == b[0]).all() and (a[1] == b[1]).all() and a[3].segments == b[3].segments
+    with pytest.raises(dray.DrayError):  # the hybrid scan cannot be forced past its staging limit
+        render_gpu(dray, gpu, spheres, cam, seed=17, variant=dray.SCAN_HYBRID)
+    d = lsb_diff(a[0], ocol)
+    report("f32_vs_oracle_grid10k_64x36_2spp", within_1lsb=float((d.max(-1) <= 1).mean()), mean=float(d.mean()),
+           segments=int(a[3].segments), oracle_segments=int(ost.segments))
+    # 2 samples per pixel: one flipped decision moves a pixel a lot, so the share is looser than at 32 spp
+    assert (d.max(-1) <= 1).mean() >= 0.95
+    assert abs(int(a[3].segments) - int(ost.segments)) <= 0.01 * ost.segments
+    mid = dray.scene_recipe(2, -35, 35, 0.8, 0.15, 0.5)
+    assert 4096 < len(mid) < 8192
+    a = render_gpu(dray, gpu, mid, cam, seed=18, variant=dray.SCAN_HYBRID)
+    b = render_gpu(dray, gpu, mid, cam, seed=18, variant=dray.SCAN_SCALAR)
+    assert (a[0] == b[0]).all() and (a[1] == b[1]).all() and a[3].segments == b[3].segments
+
+
+def test_glass_metal_depth_100(dray, gpu, oracle):
+    """Half glass, half low-fuzz metal, max_depth 100: long specular chains (refract/reflect/Schlick branches)
+    and the deepest right-to-left product the default configuration list holds."""
+    spheres = dray.scene_glass_metal(3)
+    cam = dray.camera_final(width=96, spp=8, depth=100)
+    ocol, oraw, ocnt, ost = oracle.render(ocam_from(oracle, cam), spheres, seed=23, threads=8)
+    for iterative in (0, 1):
+        cam.mode = dray.MODE_F64
+        cam.flags = dray.FLAG_ITERATIVE_PRODUCT if iterative else 0
+        col, raw, cnt, st = render_gpu(dray, gpu, spheres, cam, seed=23)
+        if not iterative:
+            assert st.segments == ost.segments
+            assert (raw == oraw).all() and lsb_diff(col, ocol).max() <= 1
+        else:  # left-to-right product: same paths, sums equal to rounding
+            assert st.segments == ost.segments
+            np.testing.assert_allclose(raw, oraw, rtol=1e-9, atol=1e-300)
+    cam.flags = 0
+    cam.mode = dray.MODE_F32
+    col, raw, cnt, st = render_gpu(dray, gpu, spheres, cam, seed=23)
+    d = lsb_diff(col, ocol)
+    report("f32_vs_oracle_glass_metal_96x54_8spp_d100", within_1lsb=float((d.max(-1) <= 1).mean()),
+           mean=float(d.mean()), max=int(d.max()), segments=int(st.segments), oracle_segments=int(ost.segments),
+           mean_path_length=float(ost.segments) / float(ost.samples))
+    # specular chains amplify a last-bit difference at every bounce: tolerance >= 90 % of pixels within 1 LSB
+    assert (d.max(-1) <= 1).mean() >= 0.90
+    assert abs(int(st.segments) - int(ost.segments)) <= 0.02 * ost.segments
+
+
+def test_full_hd_properties(dray, gpu, oracle):
+    """1920 x 1080, 100 samples per pixel, depth 50 on the three-sphere scene (the per-node workload of the
+    distributed configuration).  The oracle cannot render the frame in seconds, so: every 90th row against the
+    oracle (f64 exact, f32 by its bound), two-slab partition == whole frame, and 60 + 40 samples == 100."""
+    from dray_amd import partition
+    spheres = dray.scene_three_spheres()
+    cam = dray.camera_three_spheres(width=1920, spp=100, depth=50)
+    H = cam.initialize().image_height
+    assert H == 1080
+    oc = ocam_from(oracle, cam)
+    ocol, oraw, ocnt, ost = oracle.render(oc, spheres, seed=31, row_begin=45, row_step=90, threads=16)
+    rows = np.arange(45, H, 90)
+    cam.mode = dray.MODE_F64
+    col, raw, cnt, st = render_gpu(dray, gpu, spheres, cam, seed=31, row_begin=45, row_step=90)
+    assert st.segments == ost.segments and st.rows_rendered == len(rows)
+    assert (raw[rows] == oraw[rows]).all() and (col[rows] == ocol[rows]).all()
+    untouched = np.setdiff1d(np.arange(H), rows)
+    assert (cnt[untouched] == 0).all() and (cnt[rows] == 100).all()
+    cam.mode = dray.MODE_F32
+    full = render_gpu(dray, gpu, spheres, cam, seed=31)
+    assert full[3].samples == 1920 * 1080 * 100 and (full[2] == 100).all()
+    d = lsb_diff(full[0][rows], ocol[rows])
+    report("f32_vs_oracle_full_hd_rows", within_1lsb=float((d.max(-1) <= 1).mean()), mean=float(d.mean()),
+           max=int(d.max()), kernel_ms=float(full[3].kernel_ms), segments=int(full[3].segments))
+    assert (d.max(-1) <= 1).mean() >= 0.99  # 100 samples per pixel: tighter than the 32-sample bound
+    assert d.mean() < 0.05
+    scene = gpu.DeviceScene(spheres, 0)
+    color, raw2, count = gpu.alloc_buffers(cam, 0)
+    segs = 0
+    for r in range(2):
+        segs += gpu.render_device(cam, scene, color, raw2, count, seed=31, row_begin=r, row_step=2).segments
+    assert segs == full[3].segments
+    assert (gpu.color_to_numpy(color) == full[0]).all() and (raw2.cpu().numpy() == full[1]).all()
+    color, raw2, count = gpu.alloc_buffers(cam, 0)
+    cam.samples_per_pixel = 60
+    gpu.render_device(cam, scene, color, raw2, count, seed=31, sample_offset=0)
+    cam.samples_per_pixel = 40
+    gpu.render_device(cam, scene, color, raw2, count, seed=31, sample_offset=60)
+    scene.close()
+    assert (count.cpu().numpy() == 100).all()
+    assert (raw2.cpu().numpy() == full[1]).all() and (gpu.color_to_numpy(color) == full[0]).all()
