@@ -59,7 +59,7 @@ def main():
     ap.add_argument("--depth", type=int, default=50)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--mode", default="f32", choices=["f32", "f64", "f32plain"])
-    ap.add_argument("--samples-per-item", type=int, default=0)
+    ap.add_argument("--pixels-per-pool", type=int, default=0)
     ap.add_argument("--variant", type=int, default=0, help="f32 sphere-scan formulation: 0 auto, 1 scalar, 2 hybrid (identical images)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -86,7 +86,7 @@ def main():
     cam.seed = args.seed
     scene = ddev.DeviceScene(spheres, local_rank)
     renderer = partition.DistributedRenderer(
-        cam, partition.gpu_render_rows(scene, samples_per_item=args.samples_per_item, variant=args.variant),
+        cam, partition.gpu_render_rows(scene, pixels_per_pool=args.pixels_per_pool, variant=args.variant),
         partition.gpu_alloc(local_rank), rank=rank, world_size=world)
 
     def sync():

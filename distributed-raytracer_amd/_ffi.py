@@ -92,7 +92,7 @@ class Opts(C.Structure):
         ("device", C.c_int32),
         ("row_begin", C.c_int32),
         ("row_step", C.c_int32),
-        ("samples_per_item", C.c_int32),
+        ("pixels_per_pool", C.c_int32),
         ("variant", C.c_int32),
     ]
 

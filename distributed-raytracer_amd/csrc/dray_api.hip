@@ -296,7 +296,7 @@ int render_device_impl(const dray_camera* cam, dray_scene* scene, uint32_t* d_co
     HIP_TRY(hipMemsetAsync(scene->d_counters, 0, sizeof(DeviceCounters), stream));
     if (opts.mode == DRAY_MODE_F32) {
         const CamDev<float> c = make_cam<float>(*cam, dv);
-        const F32Plan plan = plan_render_f32(c, part, opts.samples_per_item, opts.variant, scene->dev.n_narrow_padded, scene->device);
+        const F32Plan plan = plan_render_f32(c, part, opts.pixels_per_pool, opts.variant, scene->dev.n_narrow_padded, scene->device);
         if (opts.variant == DRAY_SCAN_HYBRID && !plan.hybrid) return DRAY_ERR_UNSUPPORTED; // table beyond the LDS staging limit
         if (plan.accum_words > scene->accum_capacity) {
             if (scene->d_accum) HIP_TRY(hipFree(scene->d_accum));

@@ -84,14 +84,13 @@ hipError_t launch_render_ref_f32(const CamDev<float>& cam, const SceneDev& scene
 
 // render_f32.hip
 struct F32Plan {
-    int32_t samples_per_item; // consecutive samples of one pixel that one lane takes at a time
-    int32_t n_chunks;         // ceil(spp / samples_per_item)
+    int32_t pixels_per_pool;  // consecutive pixels a wave takes from the global queue at a time
     size_t accum_words;       // 3 * n_rows * W fixed-point sums (u64), zeroed before the launch
     int32_t grid, block;
     size_t lds_bytes;         // dynamic LDS of the launch
     int32_t hybrid;           // 1: filter + exact scan with the filter table in LDS, 0: exact scan through scalar loads
 };
-F32Plan plan_render_f32(const CamDev<float>& cam, const Partition& part, int32_t samples_per_item, int32_t variant,
+F32Plan plan_render_f32(const CamDev<float>& cam, const Partition& part, int32_t pixels_per_pool, int32_t variant,
                         int32_t n_narrow_padded, int device);
 hipError_t launch_render_f32(const CamDev<float>& cam, const SceneDev& scene, const Partition& part, const RngKey& key,
                              const F32Plan& plan, unsigned long long* d_accum, DeviceCounters* d_counters,

@@ -8,10 +8,9 @@
 // wave's pool, so all 64 lanes stay inside the sphere scan, which is the same
 // instruction stream for every lane whatever its pixel, sample or bounce.
 //
-// A work item is `samples_per_item` consecutive samples of one pixel.  Sample
-// colours are summed as 36.28 fixed-point integers (integer addition is
-// associative), so the image does not depend on the item size, the partition,
-// the GPU count or the order in which lanes finish.
+// Sample colours are summed as 36.28 fixed-point integers (integer addition is
+// associative), so the image does not depend on how samples are grouped, on
+// the partition, the GPU count or the order in which lanes finish.
 //
 // The sphere list is scanned in insertion order (hittable_list.rs:65-70).
 // "Narrow" spheres are tested in f32; "wide" spheres, whose radius is so large
@@ -34,8 +33,10 @@ constexpr float kFixScale = 268435456.f;      // 2^28
 constexpr double kFixInv = 1.0 / 268435456.0; // 2^-28
 constexpr float kFixMax = 15.99f;             // a sample colour channel is clamped to [0, 15.99]
 constexpr int kUnroll = 8;                    // spheres per scan block (the tables are padded to a multiple)
-constexpr int kPoolItems = 64;                // work items a wave takes from the global queue per atomic
+constexpr int kPoolSamples = 64;               // samples a wave aims to take from the global queue per atomic
 constexpr float kSlack = 7.62939453125e-6f;   // 2^-17, see scan_hybrid
+constexpr int kSlots = 32;                     // pixel sums a wave keeps in LDS before they go to memory
+constexpr uint32_t kNoPixel = 0xFFFFFFFFu;
 
 // Waves per SIMD the register allocation of the trace kernel aims at (7 = at most 72 VGPRs; measured fastest: 6 -> 100.6 ms, 7 -> 96.4 ms, 8 -> 102.6 ms per 1200x675x500 frame).
 #ifndef DRAY_WAVES_PER_EU
@@ -189,92 +190,126 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DRAY_WAVES_
     const float4* __restrict__ filter_zn, const int32_t* __restrict__ narrow_index,
     const int32_t* __restrict__ wide_index, const double* __restrict__ geom64, const float4* __restrict__ geom32,
     const float4* __restrict__ mat32, const uint32_t* __restrict__ kind, int32_t n_narrow_padded, int32_t n_wide,
-    Partition part, RngKey key, int32_t samples_per_item, int32_t n_chunks, unsigned long long n_items,
-    unsigned long long* __restrict__ accum, DeviceCounters* counters) {
+    Partition part, RngKey key, int32_t pixels_per_pool, unsigned long long* __restrict__ accum,
+    DeviceCounters* counters) {
     // The tables come as separate __restrict__ pointers: with that the compiler knows the wave-uniform reads of
     // the sphere tables cannot alias a store and emits scalar loads for them.
     const int lane = __lane_id();
-    const uint32_t npix = (uint32_t)part.n_rows * (uint32_t)cam.W;
+    const uint32_t W = (uint32_t)cam.W, spp = (uint32_t)cam.spp;
+    const uint32_t npix = (uint32_t)part.n_rows * W;
     extern __shared__ float4 lds_xy[]; // HYBRID: cx, cy of two consecutive narrow spheres per entry
     if constexpr (HYBRID) {
         for (int32_t k = threadIdx.x; k < n_narrow_padded / 2; k += blockDim.x) lds_xy[k] = filter_xy[k];
         __syncthreads(); // the only block-wide wait: every wave passes here once, before any work is drawn
     }
 
-    bool alive = false, done = false, have_item = false;
-    int32_t s_next = 0, s_end = 0;
-    uint32_t pix = 0;
-    int32_t pi = 0, pj = 0;
-    unsigned long long acc_r = 0, acc_g = 0, acc_b = 0;
-    uint32_t n_seg = 0, n_samples = 0;
-    unsigned long long pool_next = 0ull, pool_end = 0ull; // wave-uniform
-
-    PathRay ray = {{0.f, 0.f, 0.f}, {0.f, 0.f, 1.f}, 0.001f};
-    F3 thr = {1.f, 1.f, 1.f};
-    int32_t stage = 1;
-    Stream st = {key.k0, key.k1, 0u, 0u, 0u};
-
-    for (;;) {
-        // ---- refill ---------------------------------------------------------------------------
-        bool need_item = !alive && !done && s_next >= s_end;
-        if (need_item && have_item) { // colors.rs:38, order-free
-            atomicAdd(&accum[pix], acc_r);
-            atomicAdd(&accum[npix + pix], acc_g);
-            atomicAdd(&accum[2u * npix + pix], acc_b);
-            have_item = false;
-        }
-        // Work items come from a wave-private pool [pool_next, pool_end) that one returning atomic on the
-        // global queue head refills kPoolItems at a time, so a lane's refill usually costs no memory round trip.
-        unsigned long long want = __ballot(need_item);
-        while (want != 0ull) {
-            if (pool_next == pool_end) { // wave-uniform
-                unsigned long long base = 0ull;
-                if (lane == 0) base = atomicAdd(&counters->next_item, (unsigned long long)kPoolItems);
-                const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)base, 0);
-                const uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(base >> 32), 0);
-                pool_next = ((unsigned long long)hi << 32) | lo; // scalar registers
-                pool_end = pool_next + (unsigned long long)kPoolItems;
-            }
-            const unsigned long long avail = pool_end - pool_next;
-            const int wanted = __popcll(want);
-            const int take = (unsigned long long)wanted < avail ? wanted : (int)avail;
-            const int rank = __popcll(want & ((1ull << lane) - 1ull));
-            if (need_item && rank < take) {
-                const unsigned long long item = pool_next + (unsigned long long)rank;
-                need_item = false;
-                if (item >= n_items) {
-                    done = true; // every lane reaches this once the queue is exhausted: the wave then drains and exits
-                } else {
-                    pix = (uint32_t)(item / (unsigned long long)n_chunks);
-                    const int32_t chunk = (int32_t)(item - (unsigned long long)pix * (unsigned long long)n_chunks);
-                    const int32_t r = (int32_t)(pix / (uint32_t)cam.W);
-                    pi = (int32_t)(pix - (uint32_t)r * (uint32_t)cam.W);
-                    pj = part.row_begin + r * part.row_step;
-                    s_next = chunk * samples_per_item;
-                    s_end = min(cam.spp, s_next + samples_per_item);
-                    acc_r = acc_g = acc_b = 0ull;
-                    have_item = true;
-                    st.pixel = (uint32_t)pj * (uint32_t)cam.W + (uint32_t)pi;
+    // A wave takes whole pixels from the global queue (a pool = all samples of `pixels_per_pool` consecutive
+    // pixels) and hands the samples to its lanes one at a time, so the samples of a pixel finish in one wave.
+    // Their fixed-point sums meet in a wave-private LDS cache (the wave's pixels take its kSlots slots in turn)
+    // and go to memory once, when the slot is given to a later pixel; a sample that ends after its pixel has left
+    // the cache adds to memory directly.  Integer sums: the image is the same whatever the grouping.  LDS keeps
+    // one wave's accesses in order, and tags and sums are only ever touched by their own wave: no barrier.
+    __shared__ unsigned long long lds_sum[4][kSlots][3]; // [wave of the block][slot][r, g, b]
+    __shared__ uint32_t lds_tag[4][kSlots];              // the slot's pixel: its Philox pixel word (j * W + i)
+    const int wv = (int)(threadIdx.x >> 6);
+    if (lane < kSlots) {
+        __hip_atomic_store(&lds_tag[wv][lane], kNoPixel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        lds_sum[wv][lane][0] = lds_sum[wv][lane][1] = lds_sum[wv][lane][2] = 0ull;
+    }
+    // index of image pixel j * W + i in the launch's row partition (the sum planes and the queue count these)
+    auto partition_index = [&](uint32_t image_pixel) {
+        const uint32_t j = image_pixel / W, i = image_pixel - j * W;
+        return ((j - (uint32_t)part.row_begin) / (uint32_t)part.row_step) * W + i;
+    };
+    auto image_pixel_of = [&](uint32_t partition_pixel) {
+        const uint32_t r = partition_pixel / W, i = partition_pixel - r * W;
+        return ((uint32_t)part.row_begin + r * (uint32_t)part.row_step) * W + i;
+    };
+    // lane `l < n` retires slot `first_slot + l` and, if `retag`, gives it to partition pixel `first_pixel + l`
+    auto retire_slots = [&](uint32_t first_slot, uint32_t first_pixel, uint32_t n, bool retag) {
+        if ((uint32_t)lane < n) {
+            const uint32_t slot = (first_slot + (uint32_t)lane) & (uint32_t)(kSlots - 1);
+            const uint32_t old = __hip_atomic_load(&lds_tag[wv][slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (old != kNoPixel) {
+                const uint32_t at = partition_index(old);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const unsigned long long v = __hip_atomic_exchange(&lds_sum[wv][slot][c], 0ull, __ATOMIC_RELAXED,
+                                                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (v != 0ull) atomicAdd(&accum[(size_t)c * npix + at], v); // colors.rs:38, order-free
                 }
             }
-            pool_next += (unsigned long long)take;
-            want = __ballot(need_item);
+            __hip_atomic_store(&lds_tag[wv][slot], retag ? image_pixel_of(first_pixel + (uint32_t)lane) : kNoPixel,
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
-        if (!alive && !done) { // next sample of the item: camera.rs:224
-            st.sample = key.sample_offset + (uint32_t)s_next;
-            st.stage = 0u;
-            camera_ray(cam, pi, pj, st, ray);
-            thr = {1.f, 1.f, 1.f};
-            stage = 1;
-            s_next++;
-            n_samples++;
-            alive = true;
-        }
-        if (__ballot(alive) == 0ull) break;
+    };
 
-        if (alive) {
-            // ---- closest hit over the sphere list: hittable_list.rs:60-74 -----------------------
+    // per-lane path state
+    uint32_t gpix = 0u; // Philox pixel word j * W + i of the lane's sample
+    uint32_t ss = 0u;   // sample index within the call (24 bits) | cache slot << 24
+    int32_t stage = 0;  // 0: idle, k > 0: on the k-th segment of a path, < 0: the queue has run out
+    uint32_t n_seg = 0;
+    PathRay ray = {{0.f, 0.f, 0.f}, {0.f, 0.f, 1.f}, 0.001f};
+    F3 thr = {1.f, 1.f, 1.f};
+    // wave-uniform queue state
+    uint32_t pool_pix = 0u, pool_q = 0u, pool_n = 0u; // first pixel, next sample, sample count of the pool
+    uint32_t pool_slot = 0u, pool_pixels = 0u;         // cache slot of the pool's first pixel, pixels in the pool
+    unsigned long long n_samples = 0ull;               // samples of the pools this wave has opened
+    bool exhausted = false;
+
+    for (;;) {
+        // ---- refill: camera.rs:217-224 ------------------------------------------------------------
+        bool need = stage == 0;
+        unsigned long long want = __ballot(need);
+        while (want != 0ull) {
+            if (pool_q == pool_n && !exhausted) { // one returning atomic on the global pixel counter opens a pool
+                unsigned long long base = 0ull;
+                if (lane == 0) base = atomicAdd(&counters->next_item, (unsigned long long)pixels_per_pool);
+                const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)base, 0);
+                const uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(base >> 32), 0);
+                if (hi != 0u || lo >= npix) {
+                    exhausted = true;
+                } else {
+                    pool_slot = (pool_slot + pool_pixels) & (uint32_t)(kSlots - 1);
+                    pool_pixels = min((uint32_t)pixels_per_pool, npix - lo);
+                    pool_pix = lo;
+                    pool_q = 0u;
+                    pool_n = pool_pixels * spp;
+                    n_samples += (unsigned long long)pool_n;
+                    retire_slots(pool_slot, lo, pool_pixels, true);
+                }
+            }
+            if (exhausted) { // every idle lane gets here once the queue is empty: the wave then drains and exits
+                if (need) stage = -1;
+                break;
+            }
+            const uint32_t avail = pool_n - pool_q;
+            const uint32_t wanted = (uint32_t)__popcll(want);
+            const uint32_t take = wanted < avail ? wanted : avail;
+            const uint32_t rank = (uint32_t)__popcll(want & ((1ull << lane) - 1ull));
+            if (need && rank < take) {
+                // (two integer divisions per hand-out; replacing them by conditional steps measured no faster)
+                const uint32_t q = pool_q + rank;
+                const uint32_t dp = q / spp, smp = q - dp * spp;
+                const uint32_t pix = pool_pix + dp;
+                const uint32_t r = pix / W;
+                const int32_t pi = (int32_t)(pix - r * W), pj = part.row_begin + (int32_t)r * part.row_step;
+                gpix = (uint32_t)pj * W + (uint32_t)pi;
+                ss = smp | (((pool_slot + dp) & (uint32_t)(kSlots - 1)) << 24);
+                const Stream st = {key.k0, key.k1, gpix, key.sample_offset + smp, 0u};
+                camera_ray(cam, pi, pj, st, ray);
+                thr = {1.f, 1.f, 1.f};
+                stage = 1;
+                need = false;
+            }
+            pool_q += take;
+            want = __ballot(need);
+        }
+        if (__ballot(stage > 0) == 0ull) break;
+
+        if (stage > 0) {
             n_seg++;
+            // ---- closest hit over the sphere list: hittable_list.rs:60-74 -----------------------
             const float ox = ray.o.x, oy = ray.o.y, oz = ray.o.z, dx = ray.d.x, dy = ray.d.y, dz = ray.d.z;
             const float tmin = ray.tmin;
             ScanBest sb = {INFINITY, -1, false};
@@ -343,7 +378,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DRAY_WAVES_
                 const float4 m = mat32[bidx];
                 const bool front = dot(ray.d, hn) < 0.f; // hittable.rs:16-22
                 const F3 n = front ? hn : F3{-hn.x, -hn.y, -hn.z};
-                st.stage = (uint32_t)stage;
+                const Stream st = {key.k0, key.k1, gpix, key.sample_offset + (ss & 0xFFFFFFu), (uint32_t)stage};
                 // Every scatter that draws at all starts with block 0 of the stage (Lambertian and Metal: first
                 // unit-vector attempt; Dialectric: the reflect/refract uniform), so it is computed once for all
                 // lanes of the wave, and the unit-vector rejection loop runs once for both materials: under
@@ -396,22 +431,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DRAY_WAVES_
                 }
             }
             if (ended) { // colors.rs:38
-                acc_r += to_fixed(c.x);
-                acc_g += to_fixed(c.y);
-                acc_b += to_fixed(c.z);
-                alive = false;
+                const unsigned long long fr = to_fixed(c.x), fg = to_fixed(c.y), fb = to_fixed(c.z);
+                const uint32_t slot = ss >> 24;
+                if (__hip_atomic_load(&lds_tag[wv][slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == gpix) {
+                    __hip_atomic_fetch_add(&lds_sum[wv][slot][0], fr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(&lds_sum[wv][slot][1], fg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(&lds_sum[wv][slot][2], fb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                } else {
+                    const uint32_t at = partition_index(gpix);
+                    atomicAdd(&accum[at], fr);
+                    atomicAdd(&accum[(size_t)npix + at], fg);
+                    atomicAdd(&accum[2 * (size_t)npix + at], fb);
+                }
+                stage = 0;
             }
         }
     }
 
-    unsigned long long segs = n_seg, smps = n_samples;
-    for (int off = 32; off > 0; off >>= 1) {
-        segs += __shfl_down(segs, off, 64);
-        smps += __shfl_down(smps, off, 64);
-    }
+    retire_slots(0u, 0u, (uint32_t)kSlots, false);
+
+    unsigned long long segs = n_seg;
+    for (int off = 32; off > 0; off >>= 1) segs += __shfl_down(segs, off, 64);
     if (lane == 0) {
         atomicAdd(&counters->segments, segs);
-        atomicAdd(&counters->samples, smps);
+        atomicAdd(&counters->samples, n_samples);
     }
 }
 
@@ -441,7 +484,7 @@ __global__ __launch_bounds__(256) void resolve_f32_kernel(int32_t W, int32_t spp
 
 } // namespace
 
-F32Plan plan_render_f32(const CamDev<float>& cam, const Partition& part, int32_t samples_per_item, int32_t variant,
+F32Plan plan_render_f32(const CamDev<float>& cam, const Partition& part, int32_t pixels_per_pool, int32_t variant,
                         int32_t n_narrow_padded, int device) {
     F32Plan plan{};
     plan.block = 256;
@@ -458,20 +501,12 @@ F32Plan plan_render_f32(const CamDev<float>& cam, const Partition& part, int32_t
     if (oe == hipSuccess && occ > 0) per_cu = occ;
     plan.grid = cus * per_cu;
     const long long npix = (long long)part.n_rows * cam.W;
-    const long long lanes = (long long)plan.grid * plan.block;
-    int32_t s = samples_per_item;
-    if (s <= 0) {
-        // Measured on the 485-sphere frame: 2..8 samples per item are fastest (short items keep a wave's lanes on
-        // neighbouring pixels and the launch's tail short; 1 sample per item makes every lane's flush contend
-        // on the same three words).  Aim at ~192 items per lane within that range.
-        long long want = ((long long)cam.spp * npix) / (lanes * 192 > 0 ? lanes * 192 : 1);
-        s = (int32_t)(want < 2 ? 2 : (want > 8 ? 8 : want));
-    }
-    if (s > cam.spp) s = cam.spp > 0 ? cam.spp : 1;
-    plan.samples_per_item = s;
-    plan.n_chunks = (cam.spp + s - 1) / s;
+    const int32_t spp = cam.spp > 0 ? cam.spp : 1;
+    int32_t ppp = pixels_per_pool > 0 ? pixels_per_pool : (kPoolSamples + spp - 1) / spp; // >= kPoolSamples samples ...
+    if (ppp > kSlots / 2) ppp = kSlots / 2; // ... while the previous pool's pixels stay cached
+    plan.pixels_per_pool = ppp;
     plan.accum_words = (size_t)3 * (size_t)(npix > 0 ? npix : 0);
-    const long long blocks_needed = (npix * plan.n_chunks + plan.block - 1) / plan.block;
+    const long long blocks_needed = (npix * spp + plan.block - 1) / plan.block;
     if (blocks_needed < plan.grid) plan.grid = (int32_t)(blocks_needed > 0 ? blocks_needed : 1);
     return plan;
 }
@@ -482,18 +517,18 @@ hipError_t launch_render_f32(const CamDev<float>& cam, const SceneDev& scene, co
     const long long npix = (long long)part.n_rows * cam.W;
     if (npix <= 0 || cam.spp <= 0) return hipSuccess;
     if (npix > 0x7fffffffLL / 3) return hipErrorInvalidValue; // the kernel indexes the three sum planes with 32 bits
-    const unsigned long long n_items = (unsigned long long)npix * (unsigned long long)plan.n_chunks;
+    if (cam.spp > 0xFFFFFF) return hipErrorInvalidValue;     // a lane keeps its sample index in 24 bits
     const F32Tables& t = scene.f32;
     if (plan.hybrid)
         hipLaunchKernelGGL(render_f32_kernel<true>, dim3(plan.grid), dim3(plan.block), plan.lds_bytes, stream, cam,
                            t.narrow_geom, t.filter_xy, t.filter_zn, t.narrow_index, t.wide_index, t.geom64, t.geom32,
-                           t.mat32, t.kind, t.n_narrow_padded, t.n_wide, part, key, plan.samples_per_item, plan.n_chunks,
-                           n_items, d_accum, d_counters);
+                           t.mat32, t.kind, t.n_narrow_padded, t.n_wide, part, key, plan.pixels_per_pool, d_accum,
+                           d_counters);
     else
         hipLaunchKernelGGL(render_f32_kernel<false>, dim3(plan.grid), dim3(plan.block), 0, stream, cam, t.narrow_geom,
                            t.filter_xy, t.filter_zn, t.narrow_index, t.wide_index, t.geom64, t.geom32, t.mat32, t.kind,
-                           t.n_narrow_padded, t.n_wide, part, key, plan.samples_per_item, plan.n_chunks, n_items,
-                           d_accum, d_counters);
+                           t.n_narrow_padded, t.n_wide, part, key, plan.pixels_per_pool, d_accum,
+                           d_counters);
     return hipGetLastError();
 }
 

@@ -119,7 +119,8 @@ typedef struct dray_opts {
     int32_t device;           /* HIP device ordinal, -1 = the current device */
     int32_t row_begin;        /* scanline partition: rows row_begin, row_begin+row_step, ... */
     int32_t row_step;         /* 0 is read as 1 */
-    int32_t samples_per_item; /* f32 mode: samples per work item, 0 = library default */
+    int32_t pixels_per_pool;  /* f32 mode: consecutive pixels a wave draws from the work queue at a time,
+                                 0 = library default; the image does not depend on it */
     int32_t variant;          /* f32 mode: sphere-scan formulation, a DRAY_SCAN_* value */
 } dray_opts;
 

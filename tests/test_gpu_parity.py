@@ -156,14 +156,14 @@ def test_row_partition_invariance(dray, gpu, mode_name):
     assert (gpu.color_to_numpy(img.contiguous()) == full_col).all()
 
 
-def test_f32_item_size_invariance(dray, gpu):
-    """Fixed-point sample sums make the f32 image independent of the work-item size."""
+def test_f32_pool_size_invariance(dray, gpu):
+    """Fixed-point sample sums make the f32 image independent of how samples are grouped into pools."""
     spheres = dray.scene_final(1)
     cam = dray.camera_final(width=80, spp=10, depth=50)
     cam.mode = dray.MODE_F32
     ref = None
-    for spi in (0, 1, 3, 10):
-        col, raw, cnt, st = render_gpu(dray, gpu, spheres, cam, seed=4, samples_per_item=spi)
+    for ppp in (0, 1, 3, 16, 1000):
+        col, raw, cnt, st = render_gpu(dray, gpu, spheres, cam, seed=4, pixels_per_pool=ppp)
         if ref is None:
             ref = (col, raw, st.segments)
         else:
