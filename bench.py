@@ -49,6 +49,20 @@ def cpu_baseline(spheres, width, depth, seed):
     return one, many
 
 
+def measured_traffic(args, world):
+    """HBM bytes per trace-kernel launch from the committed PMC passes (profiles/traffic.json, written by
+    tools/ab_traffic.sh: FETCH_SIZE and WRITE_SIZE in a rocprofv3 pass each).  Counters cannot be read from
+    inside this process, so the figure applies only to the configuration those passes ran: otherwise None."""
+    default = (args.width, args.spp, args.depth, args.seed, args.mode, args.variant, args.pixels_per_pool)
+    if world != 1 or default != (1200, 500, 50, 1, "f32", 0, 0):
+        return None
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            return json.load(f)["kernels"]["render_f32_kernel"]["bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -151,7 +165,8 @@ def main():
                 "peak": PEAK_FP32_VALU / 1e12,
                 "unit": "TFLOP/s",
                 "frac": achieved / PEAK_FP32_VALU,
-                "traffic": None,
+                "traffic": measured_traffic(args, world),
+                "traffic_unit": "bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE, separate PMC passes of this command)",
                 "kernel": "render_f32_kernel" if args.mode == "f32" else "render_ref_kernel",
                 "kernel_ms": k_s * 1e3,
                 "resolve_ms": resolve_ms / max(args.steps, 1),

@@ -13,9 +13,18 @@ for c in WRITE_SIZE FETCH_SIZE; do
   timeout -s KILL 120 rocprofv3 --pmc $c --output-format csv -d "$out" -o $c -- python3 $root/bench.py --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2> "$out/err_$c.txt" || exit 1
 done
 python3 - "$out" <<'PY'
-import csv, glob, sys
+import csv, glob, json, sys
+res = {}
 for f in sorted(glob.glob(sys.argv[1] + "/*counter_collection.csv")):
     for r in csv.DictReader(open(f)):
-        if "render_f32" in r["Kernel_Name"] or "resolve" in r["Kernel_Name"]:
-            print(r["Kernel_Name"].split("(")[1][:30] if "anonymous" in r["Kernel_Name"] else r["Kernel_Name"][:40], r["Kernel_Name"][28:60], r["Counter_Name"], "KiB", r["Counter_Value"])
+        name = r["Kernel_Name"]
+        short = "render_f32_kernel" if "render_f32" in name else "resolve_f32_kernel" if "resolve" in name else None
+        if short:
+            res.setdefault(short, {})[r["Counter_Name"] + "_KiB"] = float(r["Counter_Value"])
+for k, v in res.items():
+    # FETCH_SIZE counts a wide coalesced read at half its bytes on gfx950: doubled here; WRITE_SIZE is taken as is
+    v["bytes_per_launch"] = 2 * 1024 * v.get("FETCH_SIZE_KiB", 0.0) + 1024 * v.get("WRITE_SIZE_KiB", 0.0)
+    print(k, v)
+json.dump({"command": "bench.py --steps 1 --warmup 0 --no-cpu-baseline (1200x675, 500 spp, depth 50, seed 1)",
+           "passes": "one rocprofv3 --pmc pass per counter", "kernels": res}, open(sys.argv[1] + "/traffic.json", "w"), indent=1)
 PY
