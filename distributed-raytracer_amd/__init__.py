@@ -9,7 +9,7 @@ from ._ffi import (FLAG_COMPACT_ROWS, FLAG_ITERATIVE_PRODUCT, MODE_F32, MODE_F32
                    SCAN_HYBRID, SCAN_SCALAR, DrayError)
 from .raytracer import (Camera, DefaultMaterial, Dialectric, Hittable, HittableList, Lambertian, Material, Metal,  # noqa: F401
                         Sphere, camera_final, camera_three_spheres, flatten_world, scene_final, scene_glass_metal,
-                        scene_grid_10k, scene_recipe, scene_three_spheres)
+                        scene_grid_10k, scene_recipe, scene_three_spheres, write_ppm)
 
 
 def version():

@@ -115,7 +115,7 @@ class Stats(C.Structure):
 EXPORTS = (
     "dray_version", "dray_strerror", "dray_device_count", "dray_opts_default", "dray_camera_default",
     "dray_camera_initialize", "dray_render", "dray_scene_create", "dray_scene_destroy", "dray_render_device",
-    "dray_scene_final", "dray_scene_recipe", "dray_scene_three_spheres",
+    "dray_scene_final", "dray_scene_recipe", "dray_scene_three_spheres", "dray_write_ppm",
 )
 
 _lib = None
@@ -164,6 +164,7 @@ def lib():
                                      C.c_void_p, P(Stats)]
     L.dray_scene_final.argtypes = [C.c_uint64, C.c_void_p, C.c_size_t]
     L.dray_scene_three_spheres.argtypes = [C.c_void_p, C.c_size_t]
+    L.dray_write_ppm.argtypes = [C.c_char_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
     L.dray_scene_recipe.argtypes = [C.c_uint64, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_void_p,
                                     C.c_size_t]
     _lib = L

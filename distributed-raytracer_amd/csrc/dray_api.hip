@@ -7,6 +7,7 @@
 
 #include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -566,6 +567,31 @@ int dray_scene_recipe(uint64_t seed, int32_t lo, int32_t hi, double p_diffuse, d
 
 int dray_scene_final(uint64_t seed, dray_sphere* out, size_t cap) {
     return dray_scene_recipe(seed, -11, 11, 0.8, 0.15, 0.5, out, cap);
+}
+
+int dray_write_ppm(const char* path, const uint32_t* color, int32_t width, int32_t height, int32_t binary) {
+    if (!path || !color || width <= 0 || height <= 0) return DRAY_ERR_INVALID_ARG;
+    FILE* f = std::fopen(path, binary ? "wb" : "w");
+    if (!f) return DRAY_ERR_INVALID_ARG;
+    bool ok = std::fprintf(f, "%s\n%d %d\n255\n", binary ? "P6" : "P3", width, height) > 0;
+    const size_t n = (size_t)width * (size_t)height;
+    if (binary) {
+        std::vector<unsigned char> row((size_t)width * 3u);
+        for (int32_t j = 0; j < height && ok; ++j) {
+            for (int32_t i = 0; i < width; ++i) {
+                const uint32_t c = color[(size_t)j * (size_t)width + (size_t)i];
+                row[3 * i + 0] = (unsigned char)(c >> 16);
+                row[3 * i + 1] = (unsigned char)(c >> 8);
+                row[3 * i + 2] = (unsigned char)c;
+            }
+            ok = std::fwrite(row.data(), 1, row.size(), f) == row.size();
+        }
+    } else {
+        for (size_t k = 0; k < n && ok; ++k)
+            ok = std::fprintf(f, "%u %u %u\n", (color[k] >> 16) & 255u, (color[k] >> 8) & 255u, color[k] & 255u) > 0;
+    }
+    ok = (std::fclose(f) == 0) && ok;
+    return ok ? DRAY_OK : DRAY_ERR_INTERNAL;
 }
 
 } // extern "C"

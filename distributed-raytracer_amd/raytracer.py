@@ -215,6 +215,19 @@ class Camera:
         return None  # Ok(())
 
 
+def write_ppm(path, color_buffer, width=None, height=None, binary=False):
+    """Write a colour buffer (uint32 0xFFrrggbb, [H, W] or flat with width/height given) as PPM: the image file
+    the reference's local binary opens but never writes (main.rs:8,52)."""
+    buf = np.ascontiguousarray(color_buffer, dtype=np.uint32)
+    if width is None or height is None:
+        if buf.ndim != 2:
+            raise DrayError(_ffi.ERR_INVALID_ARG, "width and height are required for a flat buffer")
+        height, width = buf.shape
+    if buf.size < int(width) * int(height):
+        raise DrayError(_ffi.ERR_BUFFER_TOO_SMALL, "colour buffer smaller than width * height")
+    _ffi.check(_ffi.lib().dray_write_ppm(str(path).encode(), buf.ctypes.data, int(width), int(height), int(bool(binary))))
+
+
 # --------------------------------------------------------------- scene recipes --
 
 def scene_final(seed=1):

@@ -184,6 +184,12 @@ int dray_scene_recipe(uint64_t seed, int32_t lo, int32_t hi, double p_diffuse, d
 /* Ground + Lambertian + Dialectric + Metal test scene (4 spheres). */
 int dray_scene_three_spheres(dray_sphere* out, size_t cap);
 
+/* ---- image output (host) -------------------------------------------------- */
+/* Writes rows [0, height) of a colour buffer (0xFFrrggbb at j*width+i, colors.rs:42) as a PPM file: plain "P3"
+ * with one "r g b" line per pixel when binary == 0, "P6" when binary != 0; maxval 255.  The reference's local
+ * binary creates img.ppm and a writer for it (main.rs:8,52) but never writes to it; this is that missing step. */
+int dray_write_ppm(const char* path, const uint32_t* color, int32_t width, int32_t height, int32_t binary);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,215 @@
+// dray.hpp -- C++ host-side mirror of the reference's scene / camera interface for the render path, over the
+// C ABI of dray.h.  Header-only; link with libdray_hip.so.
+//
+// Names, argument meaning and failure behaviour follow src/raytracer of the reference (Rust):
+//   Vec3 / Point3 / Color3            vec3.rs:5-23 (three f64, constructor order x, y, z)
+//   Lambertian / Metal / Dialectric   material.rs:39, :66-70 (fuzz clamped to 1), :89 (spelling as in the reference)
+//   DefaultMaterial                   material.rs:10-19 (absorbs every ray)
+//   Sphere::new                       sphere.rs:13-19 (radius clamped at 0)
+//   HittableList new/add/clear/len    hittable_list.rs:11-40 (insertion order is the tie-break order, :65-70)
+//   Camera: ten public fields, new()  camera.rs:41-54, :147-163
+//   Camera::render                    camera.rs:208-236, returning io::Result<()> there; here it throws dray::Error
+// Only render does work: it flattens the world and calls dray_render.
+#pragma once
+
+#include <cstdint>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "dray.h"
+
+namespace dray {
+
+struct Error : std::runtime_error {
+    int status;
+    Error(int st, const std::string& what) : std::runtime_error(what + ": " + dray_strerror(st)), status(st) {}
+};
+
+inline void check(int status, const char* what) {
+    if (status < 0) throw Error(status, what);
+}
+
+struct Vec3 {
+    double x = 0., y = 0., z = 0.;
+    Vec3() = default;
+    Vec3(double x_, double y_, double z_) : x(x_), y(y_), z(z_) {}
+};
+using Point3 = Vec3;
+using Color3 = Vec3;
+
+// ---- materials ---------------------------------------------------------------------------------------------
+class Material {
+  public:
+    virtual ~Material() = default;
+    // kind, albedo and parameter as dray_sphere carries them
+    virtual void flatten(dray_sphere& out) const = 0;
+};
+
+class DefaultMaterial : public Material {
+  public:
+    void flatten(dray_sphere& out) const override { out.kind = DRAY_MAT_DEFAULT; }
+};
+
+class Lambertian : public Material {
+  public:
+    explicit Lambertian(Color3 albedo) : albedo_(albedo) {}
+    void flatten(dray_sphere& out) const override {
+        out.kind = DRAY_MAT_LAMBERTIAN;
+        out.albedo[0] = albedo_.x; out.albedo[1] = albedo_.y; out.albedo[2] = albedo_.z;
+    }
+
+  private:
+    Color3 albedo_;
+};
+
+class Metal : public Material {
+  public:
+    Metal(Color3 albedo, double fuzz) : albedo_(albedo), fuzz_(fuzz < 1.0 ? fuzz : 1.0) {}
+    void flatten(dray_sphere& out) const override {
+        out.kind = DRAY_MAT_METAL;
+        out.albedo[0] = albedo_.x; out.albedo[1] = albedo_.y; out.albedo[2] = albedo_.z;
+        out.fuzz_or_ior = fuzz_;
+    }
+
+  private:
+    Color3 albedo_;
+    double fuzz_;
+};
+
+class Dialectric : public Material {
+  public:
+    explicit Dialectric(double refraction_index) : refraction_index_(refraction_index) {}
+    void flatten(dray_sphere& out) const override {
+        out.kind = DRAY_MAT_DIELECTRIC;
+        out.fuzz_or_ior = refraction_index_;
+    }
+
+  private:
+    double refraction_index_;
+};
+
+// ---- hittables ---------------------------------------------------------------------------------------------
+class Hittable {
+  public:
+    virtual ~Hittable() = default;
+    // appends this object's spheres in the order HittableList::hit would visit them
+    virtual void flatten(std::vector<dray_sphere>& out) const = 0;
+};
+
+class Sphere : public Hittable {
+  public:
+    Sphere(Point3 center, double radius, std::shared_ptr<Material> mat)
+        : center_(center), radius_(radius > 0. ? radius : 0.), mat_(std::move(mat)) {}
+    Point3 center() const { return center_; }
+    double radius() const { return radius_; }
+    void flatten(std::vector<dray_sphere>& out) const override {
+        dray_sphere s{};
+        s.center[0] = center_.x; s.center[1] = center_.y; s.center[2] = center_.z;
+        s.radius = radius_;
+        if (!mat_) throw Error(DRAY_ERR_UNSUPPORTED, "sphere without a material");
+        mat_->flatten(s);
+        out.push_back(s);
+    }
+
+  private:
+    Point3 center_;
+    double radius_;
+    std::shared_ptr<Material> mat_;
+};
+
+class HittableList : public Hittable {
+  public:
+    HittableList() = default;
+    explicit HittableList(std::shared_ptr<Hittable> object) { add(std::move(object)); }
+    void clear() { objects.clear(); }
+    void add(std::shared_ptr<Hittable> object) { objects.push_back(std::move(object)); }
+    size_t len() const { return objects.size(); }
+    void flatten(std::vector<dray_sphere>& out) const override {
+        for (const auto& o : objects) {
+            if (!o) throw Error(DRAY_ERR_UNSUPPORTED, "null hittable");
+            o->flatten(out);
+        }
+    }
+    std::vector<std::shared_ptr<Hittable>> objects;
+};
+
+// ---- camera ------------------------------------------------------------------------------------------------
+class Camera {
+  public:
+    double aspect_ratio = 1.0;
+    int32_t image_width = 100;
+    int32_t samples_per_pixel = 10;
+    int32_t max_depth = 10;
+    double vfov = 90.0;
+    Point3 lookfrom{0., 0., 0.};
+    Point3 lookat{0., 0., -1.};
+    Vec3 vup{0., 1., 0.};
+    double defocus_angle = 0.0;
+    double focus_dist = 10.0;
+
+    // backend options, not in the reference: see dray_opts
+    dray_opts opts;
+    dray_stats last_stats{};
+
+    Camera() { dray_opts_default(&opts); }
+    static Camera create() { return Camera(); } // Camera::new
+
+    dray_camera pod() const {
+        dray_camera c{};
+        c.aspect_ratio = aspect_ratio;
+        c.image_width = image_width;
+        c.samples_per_pixel = samples_per_pixel;
+        c.max_depth = max_depth;
+        c.vfov = vfov;
+        c.lookfrom[0] = lookfrom.x; c.lookfrom[1] = lookfrom.y; c.lookfrom[2] = lookfrom.z;
+        c.lookat[0] = lookat.x; c.lookat[1] = lookat.y; c.lookat[2] = lookat.z;
+        c.vup[0] = vup.x; c.vup[1] = vup.y; c.vup[2] = vup.z;
+        c.defocus_angle = defocus_angle;
+        c.focus_dist = focus_dist;
+        return c;
+    }
+
+    // Camera::initialize (camera.rs:169-206); also what a caller needs to size its buffers
+    dray_camera_derived initialize() const {
+        const dray_camera c = pod();
+        dray_camera_derived d{};
+        check(dray_camera_initialize(&c, &d), "Camera::initialize");
+        return d;
+    }
+    int32_t image_height() const { return initialize().image_height; }
+
+    // Camera::render.  The buffers hold at least image_width * image_height pixels (the reference's caller sizes
+    // them image_width^2, main.rs:69-73) and are added to, never cleared (colors.rs:38-39).  `present`, if
+    // given, is called once with the finished colour buffer where the reference refreshes its window after
+    // every sample (colors.rs:44).
+    template <typename Present>
+    void render(const Hittable& world, Present&& present, std::vector<uint32_t>& color_buffer,
+                std::vector<double>& raw_buffer, std::vector<int32_t>& count_buffer) {
+        std::vector<dray_sphere> spheres;
+        world.flatten(spheres);
+        const dray_camera c = pod();
+        size_t buf_len = color_buffer.size();
+        if (!raw_buffer.empty() && raw_buffer.size() / 3 < buf_len) buf_len = raw_buffer.size() / 3;
+        if (!count_buffer.empty() && count_buffer.size() < buf_len) buf_len = count_buffer.size();
+        check(dray_render(&c, spheres.empty() ? nullptr : spheres.data(), spheres.size(), color_buffer.data(),
+                          raw_buffer.empty() ? nullptr : raw_buffer.data(),
+                          count_buffer.empty() ? nullptr : count_buffer.data(), buf_len, &opts, &last_stats),
+              "Camera::render");
+        present(color_buffer, image_width, last_stats.image_height);
+    }
+    void render(const Hittable& world, std::vector<uint32_t>& color_buffer, std::vector<double>& raw_buffer,
+                std::vector<int32_t>& count_buffer) {
+        render(world, [](const std::vector<uint32_t>&, int32_t, int32_t) {}, color_buffer, raw_buffer, count_buffer);
+    }
+};
+
+inline void write_ppm(const std::string& path, const std::vector<uint32_t>& color, int32_t width, int32_t height,
+                      bool binary = false) {
+    if (color.size() < (size_t)width * (size_t)height) throw Error(DRAY_ERR_BUFFER_TOO_SMALL, "write_ppm");
+    check(dray_write_ppm(path.c_str(), color.data(), width, height, binary ? 1 : 0), "write_ppm");
+}
+
+} // namespace dray

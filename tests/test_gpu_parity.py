@@ -429,3 +429,41 @@ def test_full_hd_properties(dray, gpu, oracle):
     scene.close()
     assert (count.cpu().numpy() == 100).all()
     assert (raw2.cpu().numpy() == full[1]).all() and (gpu.color_to_numpy(color) == full[0]).all()
+
+
+def test_cpp_mirror_matches_python_binding(dray, gpu, oracle, tmp_path):
+    """The same world built through the C++ mirror classes (tests/cpp/mirror_render.cpp) and through the Python
+    mirror renders to the same file, sums and segment count; and both equal the oracle."""
+    import json
+    import os
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_host_abi import read_ppm
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cpp", "mirror_render")
+    assert os.path.exists(exe), "tests/cpp/mirror_render is built by __graft_entry__.build()"
+    ppm, rawf = str(tmp_path / "m.ppm"), str(tmp_path / "m.raw")
+    p = subprocess.run([exe, "0", "21", "48", "4", "10", ppm, rawf], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr
+    info = json.loads(p.stdout)
+    world = dray.HittableList()
+    world.add(dray.Sphere((0.0, -100.5, -1.0), 100.0, dray.Lambertian((0.8, 0.8, 0.0))))
+    world.add(dray.Sphere((0.0, 0.0, -1.2), 0.5, dray.Lambertian((0.1, 0.2, 0.5))))
+    world.add(dray.Sphere((-1.0, 0.0, -1.0), 0.5, dray.Dialectric(1.5)))
+    world.add(dray.Sphere((1.0, 0.0, -1.0), 0.5, dray.Metal((0.8, 0.6, 0.2), 3.0)))
+    world.add(dray.Sphere((0.0, 1.2, -1.5), -2.0, dray.DefaultMaterial()))
+    cam = dray.Camera.new()
+    cam.aspect_ratio, cam.image_width, cam.samples_per_pixel, cam.max_depth = 16.0 / 9.0, 48, 4, 10
+    cam.mode, cam.seed = dray.MODE_F64, 21
+    W = 48
+    color = np.zeros(W * W, dtype=np.uint32)
+    raw = np.zeros((W * W, 3), dtype=np.float64)
+    cam.render(world, None, color, raw, None)
+    H = cam.image_height
+    w, h, px = read_ppm(ppm)
+    assert (w, h) == (W, H) == (info["width"], info["height"]) and info["spheres"] == 5
+    assert (px == channels(color[:W * H].reshape(H, W)).astype(np.uint8)).all()
+    assert (np.fromfile(rawf, dtype=np.float64).reshape(H, W, 3) == raw[:W * H].reshape(H, W, 3)).all()
+    assert info["segments"] == cam.last_stats.segments
+    ocol, oraw, _, ost = oracle.render(ocam_from(oracle, cam), dray.flatten_world(world), seed=21)
+    assert (oraw == raw[:W * H].reshape(H, W, 3)).all() and ost.segments == info["segments"]

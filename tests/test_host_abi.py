@@ -139,3 +139,55 @@ def test_partition_arithmetic(dray):
             assert img.shape == (H, 5) and (img == np.arange(H)[:, None]).all()
     with pytest.raises(ValueError):
         P.row_partition(10, 2, 2)
+
+
+def read_ppm(path):
+    """(width, height, uint8[H, W, 3]) of a P3 or P6 file with maxval 255."""
+    with open(path, "rb") as f:
+        data = f.read()
+    head = data.split(None, 4)
+    magic, w, h, maxval = head[0], int(head[1]), int(head[2]), int(head[3])
+    assert maxval == 255
+    if magic == b"P6":
+        body = data[len(data) - 3 * w * h:]
+        px = np.frombuffer(body, dtype=np.uint8)
+    else:
+        assert magic == b"P3"
+        px = np.array(data.split()[4:], dtype=np.int64).astype(np.uint8)
+    return w, h, px.reshape(h, w, 3)
+
+
+def test_write_ppm_plain_and_binary(dray, tmp_path):
+    """The image file the reference opens but never writes (main.rs:8,52): P3 one pixel per line, and P6."""
+    rng = np.random.default_rng(5)
+    color = (rng.integers(0, 1 << 24, size=(5, 7), dtype=np.uint32) | np.uint32(0xFF000000))
+    want = np.stack([(color >> 16) & 255, (color >> 8) & 255, color & 255], axis=-1).astype(np.uint8)
+    for binary in (0, 1):
+        path = str(tmp_path / ("img%d.ppm" % binary))
+        dray.write_ppm(path, color, binary=bool(binary))
+        w, h, px = read_ppm(path)
+        assert (w, h) == (7, 5) and (px == want).all()
+    text = open(str(tmp_path / "img0.ppm")).read().splitlines()
+    assert text[:3] == ["P3", "7 5", "255"] and len(text) == 3 + 35
+    assert text[3] == "%d %d %d" % tuple(want[0, 0])
+    with pytest.raises(dray.DrayError):
+        dray.write_ppm(str(tmp_path / "no_such_dir" / "x.ppm"), color)
+    with pytest.raises(dray.DrayError):
+        dray.write_ppm(path, color[:0])
+
+
+def test_cpp_mirror_builds_and_fails_loudly_without_gpu(dray, tmp_path):
+    """The C++ mirror (include/dray.hpp) compiles with the host compiler alone; without a GPU its render throws
+    dray::Error carrying DRAY_ERR_NO_DEVICE instead of falling back to anything."""
+    import os
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    subprocess.run(["make", "-C", os.path.join(here, "cpp"), "--no-print-directory"], check=True,
+                   stdout=subprocess.DEVNULL)
+    exe = os.path.join(here, "cpp", "mirror_render")
+    assert os.path.exists(exe)
+    if dray.device_count() > 0:
+        pytest.skip("a GPU is visible: the failure path is not reachable")
+    p = subprocess.run([exe, "0", "21", "48", "4", "10", str(tmp_path / "x.ppm")], capture_output=True, text=True)
+    assert p.returncode == 4 and "no HIP device" in p.stderr
+    assert not (tmp_path / "x.ppm").exists()
