@@ -27,7 +27,7 @@ MAT_DEFAULT, MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC = 0, 1, 2, 3
 MODE_F64, MODE_F32, MODE_F32_PLAIN = 0, 1, 2
 FLAG_ITERATIVE_PRODUCT = 1
 FLAG_COMPACT_ROWS = 2
-SCAN_AUTO, SCAN_SCALAR, SCAN_HYBRID = 0, 1, 2
+SCAN_AUTO, SCAN_SCALAR, SCAN_HYBRID, SCAN_GRID = 0, 1, 2, 3
 
 
 class CameraPOD(C.Structure):

@@ -142,10 +142,131 @@ void scene_free(dray_scene* s) {
     (void)hipFree(d.geom32); (void)hipFree(d.mat32);
     (void)hipFree(d.narrow_geom); (void)hipFree(d.filter_xy); (void)hipFree(d.filter_zn);
     (void)hipFree(d.narrow_index); (void)hipFree(d.wide_index);
+    (void)hipFree(d.grid_cells); (void)hipFree(d.grid_entry_geom); (void)hipFree(d.grid_entry_pos); (void)hipFree(d.grid_loose);
     (void)hipFree(s->d_counters); (void)hipFree(s->d_accum);
     for (auto& e : s->ev)
         if (e) (void)hipEventDestroy(e);
     delete s;
+}
+
+// Host-side build of the uniform grid the f32 kernel's grid scan walks.
+struct GridHost {
+    GridDev dev{};
+    std::vector<uint2> cells;
+    std::vector<float> entry_geom;
+    std::vector<int32_t> entry_pos, loose;
+};
+
+constexpr int kGridMaxAxis = 256;      // cells per axis
+constexpr size_t kGridSpanLimit = 512; // a sphere overlapping more cells than this stays out of the grid
+
+// ng: narrow_geom rows (cx, cy, cz, r*r) of the first n_narrow positions.
+void build_grid(const std::vector<float>& ng, int32_t n_narrow, GridHost& g) {
+    g = GridHost();
+    if (n_narrow <= 0) return;
+    std::vector<double> rad(n_narrow);
+    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int32_t p = 0; p < n_narrow; ++p) {
+        rad[p] = std::sqrt((double)ng[4 * p + 3]) * (1.0 + 1e-6);
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = std::fmin(lo[a], (double)ng[4 * p + a] - rad[p]);
+            hi[a] = std::fmax(hi[a], (double)ng[4 * p + a] + rad[p]);
+        }
+    }
+    double ext[3], biggest = 0., reach = 0.;
+    for (int a = 0; a < 3; ++a) {
+        biggest = std::fmax(biggest, hi[a] - lo[a]);
+        reach = std::fmax(reach, std::fmax(std::fabs(lo[a]), std::fabs(hi[a])));
+    }
+    // every box below is inflated by far more than the f32 rounding of a walk or of the exact test can move a point
+    const double pad = 1e-3 * biggest + 1e-5 * reach + 1e-6;
+    for (int a = 0; a < 3; ++a) {
+        lo[a] -= pad;
+        hi[a] += pad;
+        ext[a] = hi[a] - lo[a];
+    }
+    double target = 4.0 * n_narrow; // cells aimed at
+    for (int attempt = 0;; ++attempt) {
+        int32_t n[3];
+        const double scale = std::cbrt(target / (ext[0] * ext[1] * ext[2]));
+        for (int a = 0; a < 3; ++a) {
+            const double want = std::floor(ext[a] * scale + 0.5);
+            n[a] = (int32_t)std::fmin(std::fmax(want, 1.), (double)kGridMaxAxis);
+        }
+        double cell[3], margin = INFINITY;
+        for (int a = 0; a < 3; ++a) {
+            cell[a] = ext[a] / n[a];
+            margin = std::fmin(margin, cell[a]);
+        }
+        margin = margin / 256. + 1e-5 * reach; // a sphere is listed wherever its ball grown by this overlaps
+        const size_t n_cells = (size_t)n[0] * n[1] * n[2];
+        std::vector<uint32_t> count(n_cells, 0u);
+        std::vector<char> is_loose(n_narrow, 0);
+        size_t total = 0;
+        auto for_cells = [&](int32_t p, auto&& visit) { // cells the grown ball of sphere p overlaps
+            const double r = rad[p] + margin;
+            int32_t c0[3], c1[3];
+            for (int a = 0; a < 3; ++a) {
+                c0[a] = (int32_t)std::fmax(0., std::floor(((double)ng[4 * p + a] - r - lo[a]) / cell[a]));
+                c1[a] = (int32_t)std::fmin((double)n[a] - 1., std::floor(((double)ng[4 * p + a] + r - lo[a]) / cell[a]));
+            }
+            for (int32_t z = c0[2]; z <= c1[2]; ++z)
+                for (int32_t y = c0[1]; y <= c1[1]; ++y)
+                    for (int32_t x = c0[0]; x <= c1[0]; ++x) {
+                        const int32_t c[3] = {x, y, z};
+                        double d2 = 0.;
+                        for (int a = 0; a < 3; ++a) {
+                            const double b0 = lo[a] + c[a] * cell[a], b1 = b0 + cell[a], v = (double)ng[4 * p + a];
+                            const double d = v < b0 ? b0 - v : (v > b1 ? v - b1 : 0.);
+                            d2 += d * d;
+                        }
+                        if (d2 <= r * r) visit(((size_t)z * n[1] + y) * n[0] + x);
+                    }
+        };
+        for (int32_t p = 0; p < n_narrow; ++p) {
+            size_t span = 0;
+            for_cells(p, [&](size_t) { ++span; });
+            if (span > kGridSpanLimit) {
+                is_loose[p] = 1;
+                continue;
+            }
+            for_cells(p, [&](size_t c) { ++count[c]; });
+            total += span;
+        }
+        // many entries per sphere mean the cells are too fine for the spheres' sizes: coarsen and try again
+        if (total > 24 * (size_t)n_narrow + 1024 && attempt < 12 && n_cells > 1) {
+            target /= 4.;
+            continue;
+        }
+        g.cells.resize(n_cells);
+        uint32_t at = 0;
+        for (size_t c = 0; c < n_cells; ++c) {
+            g.cells[c] = make_uint2(at, 0u);
+            at += count[c];
+        }
+        g.entry_geom.resize(4 * (size_t)total);
+        g.entry_pos.resize(total);
+        for (int32_t p = 0; p < n_narrow; ++p) { // ascending p: a cell's entries come out in insertion order
+            if (is_loose[p]) {
+                g.loose.push_back(p);
+                continue;
+            }
+            for_cells(p, [&](size_t c) {
+                const size_t e = (size_t)g.cells[c].x + g.cells[c].y++;
+                for (int q = 0; q < 4; ++q) g.entry_geom[4 * e + q] = ng[4 * p + q];
+                g.entry_pos[e] = p;
+            });
+        }
+        for (int a = 0; a < 3; ++a) {
+            g.dev.lo[a] = (float)lo[a];
+            g.dev.hi[a] = (float)hi[a];
+            g.dev.n[a] = n[a];
+            g.dev.cell[a] = (float)cell[a];
+            g.dev.inv_cell[a] = (float)(1.0 / cell[a]);
+        }
+        g.dev.n_loose = (int32_t)g.loose.size();
+        return;
+    }
 }
 
 template <typename T>
@@ -224,7 +345,21 @@ int scene_create_impl(const dray_sphere* sp, size_t n, int32_t device, dray_scen
         fzn[2 * p + 0] = cz; fzn[2 * p + 1] = nwf;
     }
 
+    GridHost grid;
+    build_grid(ng, d.n_narrow, grid);
+
     int rc = DRAY_OK;
+    if ((rc = upload(&d.grid_cells, grid.cells)) || (rc = upload(&d.grid_entry_geom, grid.entry_geom)) ||
+        (rc = upload(&d.grid_entry_pos, grid.entry_pos)) || (rc = upload(&d.grid_loose, grid.loose))) {
+        scene_free(s);
+        return rc;
+    }
+    d.grid = grid.dev;
+    d.grid.cells = d.grid_cells;
+    d.grid.entry_geom = (const float4*)d.grid_entry_geom;
+    d.grid.entry_pos = d.grid_entry_pos;
+    d.grid.loose = d.grid_loose;
+    d.grid_entries = grid.entry_pos.size();
     if ((rc = upload(&d.geom64, g64)) || (rc = upload(&d.mat64, m64)) || (rc = upload(&d.kind, kind)) ||
         (rc = upload(&d.geom32, g32)) || (rc = upload(&d.mat32, m32)) || (rc = upload(&d.narrow_geom, ng)) ||
         (rc = upload(&d.filter_xy, fxy)) || (rc = upload(&d.filter_zn, fzn)) ||
@@ -260,7 +395,7 @@ int render_device_impl(const dray_camera* cam, dray_scene* scene, uint32_t* d_co
     if (!camera_ok(cam) || !scene || !d_color) return DRAY_ERR_INVALID_ARG;
     dray_opts opts;
     if (opts_in) opts = *opts_in; else dray_opts_default(&opts);
-    if (opts.mode > DRAY_MODE_F32_PLAIN || opts.variant < 0 || opts.variant > DRAY_SCAN_HYBRID) return DRAY_ERR_INVALID_ARG;
+    if (opts.mode > DRAY_MODE_F32_PLAIN || opts.variant < 0 || opts.variant > DRAY_SCAN_GRID) return DRAY_ERR_INVALID_ARG;
     if (opts.row_step == 0) opts.row_step = 1;
     if (opts.row_step < 0 || opts.row_begin < 0) return DRAY_ERR_INVALID_ARG;
     if (opts.device >= 0 && opts.device != scene->device) return DRAY_ERR_INVALID_ARG;
@@ -297,8 +432,8 @@ int render_device_impl(const dray_camera* cam, dray_scene* scene, uint32_t* d_co
     HIP_TRY(hipMemsetAsync(scene->d_counters, 0, sizeof(DeviceCounters), stream));
     if (opts.mode == DRAY_MODE_F32) {
         const CamDev<float> c = make_cam<float>(*cam, dv);
-        const F32Plan plan = plan_render_f32(c, part, opts.pixels_per_pool, opts.variant, scene->dev.n_narrow_padded, scene->device);
-        if (opts.variant == DRAY_SCAN_HYBRID && !plan.hybrid) return DRAY_ERR_UNSUPPORTED; // table beyond the LDS staging limit
+        const F32Plan plan = plan_render_f32(c, part, opts.pixels_per_pool, opts.variant, scene->dev, scene->device);
+        if (opts.variant == DRAY_SCAN_HYBRID && plan.scan != DRAY_SCAN_HYBRID) return DRAY_ERR_UNSUPPORTED; // table beyond the LDS staging limit
         if (plan.accum_words > scene->accum_capacity) {
             if (scene->d_accum) HIP_TRY(hipFree(scene->d_accum));
             scene->d_accum = nullptr;

@@ -46,6 +46,21 @@ struct F32Tables {
     int32_t n_wide = 0;
 };
 
+// Uniform grid over the narrow spheres, walked by the f32 kernel's grid scan.  A sphere is entered in every cell
+// its slightly inflated ball overlaps; spheres that would span too many cells stay outside ("loose") and are
+// tested against every ray.
+struct GridDev {
+    float lo[3], hi[3];  // the grid's box (holds every listed sphere, inflated)
+    float cell[3];       // cell size per axis
+    float inv_cell[3];
+    int32_t n[3];        // cells per axis; n[0] == 0: no grid (no narrow spheres)
+    int32_t n_loose;
+    const uint2* cells = nullptr;       // per cell (x fastest): first entry, entry count
+    const float4* entry_geom = nullptr; // per entry: cx, cy, cz, r*r (the sphere's narrow_geom row)
+    const int32_t* entry_pos = nullptr; // per entry: the sphere's position in the narrow table; ascending in a cell
+    const int32_t* loose = nullptr;     // narrow positions of the loose spheres, ascending
+};
+
 // Sphere tables in device memory (owned by the scene).
 struct SceneDev {
     int32_t n = 0;
@@ -63,6 +78,13 @@ struct SceneDev {
     int32_t* narrow_index = nullptr;
     int32_t* wide_index = nullptr;
     F32Tables f32; // the pointers above, as the f32 kernel takes them
+    // grid scan
+    uint2* grid_cells = nullptr;
+    float* grid_entry_geom = nullptr;
+    int32_t* grid_entry_pos = nullptr;
+    int32_t* grid_loose = nullptr;
+    size_t grid_entries = 0;
+    GridDev grid{};
 };
 
 constexpr size_t kHybridLdsLimit = 64 * 1024; // largest cx,cy table (8 B per sphere) the hybrid scan stages in LDS
@@ -88,10 +110,10 @@ struct F32Plan {
     size_t accum_words;       // 3 * n_rows * W fixed-point sums (u64), zeroed before the launch
     int32_t grid, block;
     size_t lds_bytes;         // dynamic LDS of the launch
-    int32_t hybrid;           // 1: filter + exact scan with the filter table in LDS, 0: exact scan through scalar loads
+    int32_t scan;             // the DRAY_SCAN_* formulation the launch uses (never DRAY_SCAN_AUTO)
 };
 F32Plan plan_render_f32(const CamDev<float>& cam, const Partition& part, int32_t pixels_per_pool, int32_t variant,
-                        int32_t n_narrow_padded, int device);
+                        const SceneDev& scene, int device);
 hipError_t launch_render_f32(const CamDev<float>& cam, const SceneDev& scene, const Partition& part, const RngKey& key,
                              const F32Plan& plan, unsigned long long* d_accum, DeviceCounters* d_counters,
                              hipStream_t stream);

@@ -43,6 +43,17 @@ constexpr uint32_t kNoPixel = 0xFFFFFFFFu;
 #define DRAY_WAVES_PER_EU 7
 #endif
 
+// Pointer into the constant address space: a wave-uniform read through it is a scalar load that the compiler
+// knows no store can alias.  The sphere tables and the kernel's own arguments are read this way.
+#define DRAY_CONSTANT __attribute__((address_space(4)))
+typedef float V4 __attribute__((ext_vector_type(4))); // a float4 that can be read through any address space
+template <typename T>
+using ConstPtr = const DRAY_CONSTANT T*;
+template <typename T>
+__device__ __forceinline__ ConstPtr<T> as_constant(const T* p) {
+    return (ConstPtr<T>)p;
+}
+
 struct F3 {
     float x, y, z;
 };
@@ -78,7 +89,8 @@ __device__ __forceinline__ void set_dir(PathRay& r, F3 dir) {
 }
 
 // camera.rs:238-262
-__device__ __forceinline__ void camera_ray(const CamDev<float>& cam, int32_t i, int32_t j, const Stream& st, PathRay& r) {
+__device__ __forceinline__ void camera_ray(ConstPtr<CamDev<float>> camp, int32_t i, int32_t j, const Stream& st, PathRay& r) {
+    const DRAY_CONSTANT CamDev<float>& cam = *camp;
     uint32_t w[4];
     st.block(0, w);
     const float fx = (float)i + (u01<float>(w[0]) - 0.5f), fy = (float)j + (u01<float>(w[1]) - 0.5f);
@@ -116,7 +128,8 @@ struct ScanBest {
 
 // The exact f32 test of one narrow sphere, sphere.rs:29-48 with |d| = 1: disc = h^2 - (|oc|^2 - r^2).
 // geom = cx, cy, cz, r^2.
-__device__ __forceinline__ void exact_test(ScanBest& b, const float4 s, const PathRay& ray, int32_t pos) {
+template <typename V>
+__device__ __forceinline__ void exact_test(ScanBest& b, const V s, const PathRay& ray, int32_t pos) {
     const float ocx = s.x - ray.o.x, ocy = s.y - ray.o.y, ocz = s.z - ray.o.z;
     const float h = fmaf(ocz, ray.d.z, fmaf(ocy, ray.d.y, ocx * ray.d.x));
     const float q = fmaf(-ocz, ocz, fmaf(-ocy, ocy, fmaf(-ocx, ocx, s.w)));
@@ -137,7 +150,7 @@ __device__ __forceinline__ void exact_test(ScanBest& b, const float4 s, const Pa
 // Scalar scan: the exact test on every sphere, 11 VALU operations per test of which 4 take an SGPR operand.
 // The table address is the same for all lanes, so the geometry arrives through scalar loads (two
 // s_load_dwordx16 per 8 spheres).  Used when the filter table does not fit in LDS, and as the A/B baseline.
-__device__ __forceinline__ void scan_scalar(const float4* __restrict__ narrow_geom, int32_t n_padded, const PathRay& ray,
+__device__ __forceinline__ void scan_scalar(ConstPtr<V4> narrow_geom, int32_t n_padded, const PathRay& ray,
                                             ScanBest& b) {
     for (int32_t k = 0; k < n_padded; k += kUnroll) {
 #pragma unroll
@@ -155,8 +168,8 @@ __device__ __forceinline__ void scan_scalar(const float4* __restrict__ narrow_ge
 // 485-sphere scene) then take the exact test.  Results are therefore identical to scan_scalar's.
 // Operand sources: cx, cy of two spheres per wave-uniform ds_read_b128 (LDS, VGPR operands); cz and nw through
 // scalar loads (3 SGPR-sourced operations per test).
-__device__ __forceinline__ void scan_hybrid(const float4* lds_xy, const float4* __restrict__ filter_zn,
-                                            const float4* __restrict__ narrow_geom, int32_t n_padded, const PathRay& ray,
+__device__ __forceinline__ void scan_hybrid(const V4* lds_xy, ConstPtr<V4> filter_zn,
+                                            ConstPtr<V4> narrow_geom, int32_t n_padded, const PathRay& ray,
                                             ScanBest& b) {
     const float dx = ray.d.x, dy = ray.d.y, dz = ray.d.z;
     const float ox2 = 2.f * ray.o.x, oy2 = 2.f * ray.o.y, oz2 = 2.f * ray.o.z;
@@ -167,8 +180,8 @@ __device__ __forceinline__ void scan_hybrid(const float4* lds_xy, const float4* 
         float lhs[kUnroll], rhs[kUnroll];
 #pragma unroll
         for (int32_t u = 0; u < kUnroll; u += 2) {
-            const float4 xy = lds_xy[(k + u) >> 1];    // cx0, cy0, cx1, cy1
-            const float4 zn = filter_zn[(k + u) >> 1]; // cz0, nw0, cz1, nw1
+            const V4 xy = lds_xy[(k + u) >> 1];    // cx0, cy0, cx1, cy1
+            const V4 zn = filter_zn[(k + u) >> 1]; // cz0, nw0, cz1, nw1
             const float h0 = fmaf(dz, zn.x, fmaf(dy, xy.y, fmaf(dx, xy.x, ndo)));
             const float q0 = fmaf(oz2, zn.x, fmaf(oy2, xy.y, fmaf(ox2, xy.x, noo)));
             lhs[u] = fmaf(h0, h0, q0);
@@ -184,22 +197,158 @@ __device__ __forceinline__ void scan_hybrid(const float4* lds_xy, const float4* 
     }
 }
 
-template <bool HYBRID>
+constexpr int kScanScalar = DRAY_SCAN_SCALAR, kScanHybrid = DRAY_SCAN_HYBRID, kScanGrid = DRAY_SCAN_GRID;
+
+// The exact test for a scan that does not visit the spheres in insertion order: on equal t the sphere inserted
+// earlier wins explicitly (hittable_list.rs:65-70 keeps the first of equals).
+template <typename V>
+__device__ __forceinline__ void exact_test_unordered(ScanBest& b, const V s, const PathRay& ray, int32_t pos) {
+    const float ocx = s.x - ray.o.x, ocy = s.y - ray.o.y, ocz = s.z - ray.o.z;
+    const float h = fmaf(ocz, ray.d.z, fmaf(ocy, ray.d.y, ocx * ray.d.x));
+    const float q = fmaf(-ocz, ocz, fmaf(-ocy, ocy, fmaf(-ocx, ocx, s.w)));
+    const float disc = fmaf(h, h, q);
+    if (disc >= 0.f) {
+        const float sq = fsqrt(disc);
+        const float t0 = h - sq;
+        const bool far = !(t0 > ray.tmin);
+        const float t = far ? h + sq : t0;
+        if (t > ray.tmin && (t < b.t || (t == b.t && pos < b.pos))) {
+            b.t = t;
+            b.pos = pos;
+            b.far = far;
+        }
+    }
+}
+
+// Grid scan: every lane walks its own ray through the uniform grid (3-D DDA) and applies the exact test to the
+// spheres listed in the cells it crosses, front to back, until the closest accepted root lies before the exit of
+// the current cell.  The result is the minimum over (t, insertion position) of the accepted roots, which is what
+// the scalar scan returns, provided no sphere the exact test would accept at the minimum is skipped:
+//   * a sphere is listed in every cell its ball, grown by 1/256 of a cell, overlaps, and the grid box holds all
+//     grown balls: the f32 rounding of the walk (positions good to ~1e-6 of the scene size) or of the exact test
+//     cannot move a ray or a root across that margin;
+//   * the walk stops only when the best root is before the cell's exit by more than the exit's rounding error;
+//   * boundary times are recomputed from the integer cell index each step, never accumulated.
+// Spheres spanning too many cells are kept in a short list every ray tests first.
+__device__ __forceinline__ void scan_grid(ConstPtr<GridDev> gp, ConstPtr<V4> narrow_geom, const PathRay& ray,
+                                          ScanBest& b) {
+    const DRAY_CONSTANT GridDev& g = *gp;
+    for (int32_t k = 0; k < g.n_loose; ++k) { // wave-uniform
+        const int32_t pos = g.loose[k];
+        exact_test_unordered(b, narrow_geom[pos], ray, pos);
+    }
+    if (g.n[0] == 0) return;
+    const float o[3] = {ray.o.x, ray.o.y, ray.o.z}, d[3] = {ray.d.x, ray.d.y, ray.d.z};
+    float A[3], B[3]; // time at which the ray reaches plane k of an axis: fma(k, A, B)
+    int32_t ahead[3]; // 1 when the ray moves towards larger indices on the axis
+    float t_in = 0.f, t_out = INFINITY, bmax = 0.f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        ahead[a] = d[a] >= 0.f ? 1 : 0;
+        if (fabsf(d[a]) > 1e-12f) {
+            const float inv = rcp(d[a]);
+            A[a] = g.cell[a] * inv;
+            B[a] = (g.lo[a] - o[a]) * inv;
+            const float t0 = B[a], t1 = (g.hi[a] - o[a]) * inv;
+            t_in = fmaxf(t_in, fminf(t0, t1));
+            t_out = fminf(t_out, fmaxf(t0, t1));
+            bmax = fmaxf(bmax, fabsf(B[a]));
+        } else { // parallel to the axis' planes: never crosses one; misses the grid if outside its slab
+            A[a] = 0.f;
+            B[a] = INFINITY;
+            if (o[a] < g.lo[a] || o[a] > g.hi[a]) t_out = -INFINITY;
+        }
+    }
+    const float slack = bmax * 3.814697265625e-6f; // 2^-18 of the largest term the boundary times are formed from
+    bool walking = t_in <= t_out + slack;
+    int32_t c[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float at = (fmaf(d[a], t_in, o[a]) - g.lo[a]) * g.inv_cell[a];
+        c[a] = min(max((int32_t)floorf(at), 0), g.n[a] - 1);
+    }
+    uint32_t e = 0u, e_end = 0u;
+    if (walking) {
+        const uint2 rec = g.cells[(c[2] * g.n[1] + c[1]) * g.n[0] + c[0]];
+        e = rec.x;
+        e_end = rec.x + rec.y;
+    }
+    while (__ballot(walking) != 0ull) {
+        if (walking) {
+            if (e == e_end) { // this cell is done: stop, or step into the next one
+                const float tx = fmaf((float)(c[0] + ahead[0]), A[0], B[0]);
+                const float ty = fmaf((float)(c[1] + ahead[1]), A[1], B[1]);
+                const float tz = fmaf((float)(c[2] + ahead[2]), A[2], B[2]);
+                const float t_exit = fminf(tx, fminf(ty, tz));
+                if (b.t < fmaf(t_exit, 1.f - 3.814697265625e-6f, -slack)) {
+                    walking = false;
+                } else {
+                    const int axis = (tx <= ty && tx <= tz) ? 0 : (ty <= tz ? 1 : 2);
+                    if (axis == 0) c[0] += ahead[0] ? 1 : -1;
+                    if (axis == 1) c[1] += ahead[1] ? 1 : -1;
+                    if (axis == 2) c[2] += ahead[2] ? 1 : -1;
+                    if ((uint32_t)c[0] >= (uint32_t)g.n[0] || (uint32_t)c[1] >= (uint32_t)g.n[1] ||
+                        (uint32_t)c[2] >= (uint32_t)g.n[2]) {
+                        walking = false;
+                    } else {
+                        const uint2 rec = g.cells[(c[2] * g.n[1] + c[1]) * g.n[0] + c[0]];
+                        e = rec.x;
+                        e_end = rec.x + rec.y;
+                    }
+                }
+            }
+            if (walking && e != e_end) {
+                exact_test_unordered(b, g.entry_geom[e], ray, g.entry_pos[e]);
+                ++e;
+            }
+        }
+    }
+}
+
+// Everything a launch of the trace kernel is given.
+struct F32Args {
+    CamDev<float> cam;
+    const V4* narrow_geom;
+    const V4* filter_xy;
+    const V4* filter_zn;
+    const int32_t* narrow_index;
+    const int32_t* wide_index;
+    const double* geom64;
+    const V4* geom32;
+    const V4* mat32;
+    const uint32_t* kind;
+    int32_t n_narrow_padded, n_wide;
+    GridDev grid;
+    Partition part;
+    RngKey key;
+    int32_t pixels_per_pool;
+    unsigned long long* accum;
+    DeviceCounters* counters;
+};
+
+// Hides where a pointer came from, so that reads through it are not moved across this point.
+template <typename T>
+__device__ __forceinline__ ConstPtr<T> opaque(ConstPtr<T> p) {
+    unsigned long long v = (unsigned long long)p;
+    asm volatile("" : "+s"(v));
+    return (ConstPtr<T>)v;
+}
+
+template <int SCAN>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DRAY_WAVES_PER_EU, DRAY_WAVES_PER_EU))) void render_f32_kernel(
-    CamDev<float> cam, const float4* __restrict__ narrow_geom, const float4* __restrict__ filter_xy,
-    const float4* __restrict__ filter_zn, const int32_t* __restrict__ narrow_index,
-    const int32_t* __restrict__ wide_index, const double* __restrict__ geom64, const float4* __restrict__ geom32,
-    const float4* __restrict__ mat32, const uint32_t* __restrict__ kind, int32_t n_narrow_padded, int32_t n_wide,
-    Partition part, RngKey key, int32_t pixels_per_pool, unsigned long long* __restrict__ accum,
-    DeviceCounters* counters) {
-    // The tables come as separate __restrict__ pointers: with that the compiler knows the wave-uniform reads of
-    // the sphere tables cannot alias a store and emits scalar loads for them.
+    F32Args args_in_kernarg_segment) {
+    // The arguments (some sixty scalar registers' worth) are read where they are used, straight from the kernel
+    // argument segment, and the pointer to it is made opaque once per path segment.  Left to itself the compiler
+    // loads them all above the main loop, runs out of scalar registers and spills inside the sphere scan -- where a
+    // change anywhere else in the kernel then decides how many reloads the scan carries.
+    (void)args_in_kernarg_segment;
+    ConstPtr<F32Args> a = (ConstPtr<F32Args>)__builtin_amdgcn_kernarg_segment_ptr();
     const int lane = __lane_id();
-    const uint32_t W = (uint32_t)cam.W, spp = (uint32_t)cam.spp;
-    const uint32_t npix = (uint32_t)part.n_rows * W;
-    extern __shared__ float4 lds_xy[]; // HYBRID: cx, cy of two consecutive narrow spheres per entry
-    if constexpr (HYBRID) {
-        for (int32_t k = threadIdx.x; k < n_narrow_padded / 2; k += blockDim.x) lds_xy[k] = filter_xy[k];
+    extern __shared__ V4 lds_xy[]; // hybrid scan: cx, cy of two consecutive narrow spheres per entry
+    if constexpr (SCAN == kScanHybrid) {
+        const int32_t half = a->n_narrow_padded / 2;
+        ConstPtr<V4> filter_xy = as_constant(a->filter_xy);
+        for (int32_t k = threadIdx.x; k < half; k += blockDim.x) lds_xy[k] = filter_xy[k];
         __syncthreads(); // the only block-wide wait: every wave passes here once, before any work is drawn
     }
 
@@ -218,13 +367,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DRAY_WAVES_
     }
     // index of image pixel j * W + i in the launch's row partition (the sum planes and the queue count these)
     auto partition_index = [&](uint32_t image_pixel) {
+        const uint32_t W = (uint32_t)a->cam.W;
         const uint32_t j = image_pixel / W, i = image_pixel - j * W;
-        return ((j - (uint32_t)part.row_begin) / (uint32_t)part.row_step) * W + i;
+        return ((j - (uint32_t)a->part.row_begin) / (uint32_t)a->part.row_step) * W + i;
     };
     auto image_pixel_of = [&](uint32_t partition_pixel) {
+        const uint32_t W = (uint32_t)a->cam.W;
         const uint32_t r = partition_pixel / W, i = partition_pixel - r * W;
-        return ((uint32_t)part.row_begin + r * (uint32_t)part.row_step) * W + i;
+        return ((uint32_t)a->part.row_begin + r * (uint32_t)a->part.row_step) * W + i;
     };
+    auto pixel_count = [&]() { return (uint32_t)a->part.n_rows * (uint32_t)a->cam.W; };
     // lane `l < n` retires slot `first_slot + l` and, if `retag`, gives it to partition pixel `first_pixel + l`
     auto retire_slots = [&](uint32_t first_slot, uint32_t first_pixel, uint32_t n, bool retag) {
         if ((uint32_t)lane < n) {
@@ -236,7 +388,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DRAY_WAVES_
                 for (int c = 0; c < 3; ++c) {
                     const unsigned long long v = __hip_atomic_exchange(&lds_sum[wv][slot][c], 0ull, __ATOMIC_RELAXED,
                                                                        __HIP_MEMORY_SCOPE_WORKGROUP);
-                    if (v != 0ull) atomicAdd(&accum[(size_t)c * npix + at], v); // colors.rs:38, order-free
+                    if (v != 0ull) atomicAdd(&a->accum[(size_t)c * pixel_count() + at], v); // colors.rs:38, order-free
                 }
             }
             __hip_atomic_store(&lds_tag[wv][slot], retag ? image_pixel_of(first_pixel + (uint32_t)lane) : kNoPixel,
@@ -258,20 +410,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DRAY_WAVES_
     bool exhausted = false;
 
     for (;;) {
+        a = opaque(a);
         // ---- refill: camera.rs:217-224 ------------------------------------------------------------
         bool need = stage == 0;
         unsigned long long want = __ballot(need);
         while (want != 0ull) {
+            const uint32_t W = (uint32_t)a->cam.W, spp = (uint32_t)a->cam.spp;
             if (pool_q == pool_n && !exhausted) { // one returning atomic on the global pixel counter opens a pool
+                const uint32_t npix = pixel_count(), pixels_per_pool = (uint32_t)a->pixels_per_pool;
                 unsigned long long base = 0ull;
-                if (lane == 0) base = atomicAdd(&counters->next_item, (unsigned long long)pixels_per_pool);
+                if (lane == 0) base = atomicAdd(&a->counters->next_item, (unsigned long long)pixels_per_pool);
                 const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)base, 0);
                 const uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(base >> 32), 0);
                 if (hi != 0u || lo >= npix) {
                     exhausted = true;
                 } else {
                     pool_slot = (pool_slot + pool_pixels) & (uint32_t)(kSlots - 1);
-                    pool_pixels = min((uint32_t)pixels_per_pool, npix - lo);
+                    pool_pixels = min(pixels_per_pool, npix - lo);
                     pool_pix = lo;
                     pool_q = 0u;
                     pool_n = pool_pixels * spp;
@@ -293,11 +448,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DRAY_WAVES_
                 const uint32_t dp = q / spp, smp = q - dp * spp;
                 const uint32_t pix = pool_pix + dp;
                 const uint32_t r = pix / W;
-                const int32_t pi = (int32_t)(pix - r * W), pj = part.row_begin + (int32_t)r * part.row_step;
+                const int32_t pi = (int32_t)(pix - r * W), pj = a->part.row_begin + (int32_t)r * a->part.row_step;
                 gpix = (uint32_t)pj * W + (uint32_t)pi;
                 ss = smp | (((pool_slot + dp) & (uint32_t)(kSlots - 1)) << 24);
-                const Stream st = {key.k0, key.k1, gpix, key.sample_offset + smp, 0u};
-                camera_ray(cam, pi, pj, st, ray);
+                const Stream st = {a->key.k0, a->key.k1, gpix, a->key.sample_offset + smp, 0u};
+                camera_ray(&a->cam, pi, pj, st, ray);
                 thr = {1.f, 1.f, 1.f};
                 stage = 1;
                 need = false;
@@ -313,17 +468,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DRAY_WAVES_
             const float ox = ray.o.x, oy = ray.o.y, oz = ray.o.z, dx = ray.d.x, dy = ray.d.y, dz = ray.d.z;
             const float tmin = ray.tmin;
             ScanBest sb = {INFINITY, -1, false};
-            if constexpr (HYBRID)
-                scan_hybrid(lds_xy, filter_zn, narrow_geom, n_narrow_padded, ray, sb);
+            if constexpr (SCAN == kScanHybrid)
+                scan_hybrid(lds_xy, as_constant(a->filter_zn), as_constant(a->narrow_geom), a->n_narrow_padded, ray, sb);
+            else if constexpr (SCAN == kScanGrid)
+                scan_grid(&a->grid, as_constant(a->narrow_geom), ray, sb);
             else
-                scan_scalar(narrow_geom, n_narrow_padded, ray, sb);
+                scan_scalar(as_constant(a->narrow_geom), a->n_narrow_padded, ray, sb);
             float best = sb.t;
             // Re-evaluate the winner from the perpendicular remainder |oc - h d|, which does not cancel.
             int32_t bidx = -1; // position in the caller's list
             F3 hp = {0.f, 0.f, 0.f}, hn = {0.f, 0.f, 0.f};
             if (sb.pos >= 0) {
-                bidx = narrow_index[sb.pos];
-                const float4 s = geom32[bidx];
+                bidx = as_constant(a->narrow_index)[sb.pos];
+                const V4 s = as_constant(a->geom32)[bidx];
                 const F3 oc = {s.x - ox, s.y - oy, s.z - oz};
                 const float h = dot(oc, ray.d);
                 const F3 l = {fmaf(-h, dx, oc.x), fmaf(-h, dy, oc.y), fmaf(-h, dz, oc.z)};
@@ -334,6 +491,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DRAY_WAVES_
                 const float ir = rcp(s.w);
                 hn = {(hp.x - s.x) * ir, (hp.y - s.y) * ir, (hp.z - s.z) * ir}; // sphere.rs:52
             }
+            const int32_t n_wide = a->n_wide;
+            ConstPtr<int32_t> wide_index = as_constant(a->wide_index);
+            ConstPtr<double> geom64 = as_constant(a->geom64);
             for (int32_t wq = 0; wq < n_wide; ++wq) {
                 // sphere.rs:28-57 in f64 for a sphere too large for f32: the cancelling terms (oc, |oc|^2 - r^2,
                 // the discriminant, the hit point relative to the centre) are f64; divisions are avoided
@@ -374,11 +534,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DRAY_WAVES_
                 const float w = 1.0f - a;
                 c = {thr.x * fmaf(a, 0.5f, w), thr.y * fmaf(a, 0.7f, w), thr.z * fmaf(a, 1.0f, w)};
             } else {
-                const uint32_t mk = kind[bidx];
-                const float4 m = mat32[bidx];
+                const uint32_t mk = as_constant(a->kind)[bidx];
+                const V4 m = as_constant(a->mat32)[bidx];
                 const bool front = dot(ray.d, hn) < 0.f; // hittable.rs:16-22
                 const F3 n = front ? hn : F3{-hn.x, -hn.y, -hn.z};
-                const Stream st = {key.k0, key.k1, gpix, key.sample_offset + (ss & 0xFFFFFFu), (uint32_t)stage};
+                const Stream st = {a->key.k0, a->key.k1, gpix, a->key.sample_offset + (ss & 0xFFFFFFu), (uint32_t)stage};
                 // Every scatter that draws at all starts with block 0 of the stage (Lambertian and Metal: first
                 // unit-vector attempt; Dialectric: the reflect/refract uniform), so it is computed once for all
                 // lanes of the wave, and the unit-vector rejection loop runs once for both materials: under
@@ -423,7 +583,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DRAY_WAVES_
                 }
                 if (scattered) {
                     stage++;
-                    if (stage <= cam.max_depth) { // camera.rs:265: the next call would still have depth > 0
+                    if (stage <= a->cam.max_depth) { // camera.rs:265: the next call would still have depth > 0
                         ray.o = hp;
                         set_dir(ray, nd);
                         ended = false;
@@ -438,10 +598,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DRAY_WAVES_
                     __hip_atomic_fetch_add(&lds_sum[wv][slot][1], fg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     __hip_atomic_fetch_add(&lds_sum[wv][slot][2], fb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 } else {
-                    const uint32_t at = partition_index(gpix);
-                    atomicAdd(&accum[at], fr);
-                    atomicAdd(&accum[(size_t)npix + at], fg);
-                    atomicAdd(&accum[2 * (size_t)npix + at], fb);
+                    const uint32_t at = partition_index(gpix), npix = pixel_count();
+                    atomicAdd(&a->accum[at], fr);
+                    atomicAdd(&a->accum[(size_t)npix + at], fg);
+                    atomicAdd(&a->accum[2 * (size_t)npix + at], fb);
                 }
                 stage = 0;
             }
@@ -453,8 +613,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DRAY_WAVES_
     unsigned long long segs = n_seg;
     for (int off = 32; off > 0; off >>= 1) segs += __shfl_down(segs, off, 64);
     if (lane == 0) {
-        atomicAdd(&counters->segments, segs);
-        atomicAdd(&counters->samples, n_samples);
+        atomicAdd(&a->counters->segments, segs);
+        atomicAdd(&a->counters->samples, n_samples);
     }
 }
 
@@ -484,20 +644,31 @@ __global__ __launch_bounds__(256) void resolve_f32_kernel(int32_t W, int32_t spp
 
 } // namespace
 
+template <int SCAN>
+hipError_t occupancy_of(int* occ, int block, size_t lds) {
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(occ, render_f32_kernel<SCAN>, block, lds);
+}
+
 F32Plan plan_render_f32(const CamDev<float>& cam, const Partition& part, int32_t pixels_per_pool, int32_t variant,
-                        int32_t n_narrow_padded, int device) {
+                        const SceneDev& scene, int device) {
     F32Plan plan{};
     plan.block = 256;
-    const size_t table_bytes = (size_t)n_narrow_padded * 8u; // cx, cy per sphere
-    plan.hybrid = variant == DRAY_SCAN_SCALAR ? 0 : (table_bytes <= kHybridLdsLimit ? 1 : 0);
-    plan.lds_bytes = plan.hybrid ? table_bytes : 0u;
+    const size_t table_bytes = (size_t)scene.n_narrow_padded * 8u; // cx, cy per sphere
+    const bool hybrid_fits = table_bytes <= kHybridLdsLimit;
+    if (variant == DRAY_SCAN_AUTO) // a grid walk pays once a ray would otherwise test a few dozen spheres
+        plan.scan = scene.n_narrow >= 64 ? DRAY_SCAN_GRID : (hybrid_fits ? DRAY_SCAN_HYBRID : DRAY_SCAN_SCALAR);
+    else if (variant == DRAY_SCAN_HYBRID)
+        plan.scan = hybrid_fits ? DRAY_SCAN_HYBRID : DRAY_SCAN_SCALAR;
+    else
+        plan.scan = variant;
+    plan.lds_bytes = plan.scan == DRAY_SCAN_HYBRID ? table_bytes : 0u;
     int cus = 256, per_cu = 4;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
     int occ = 0;
-    const hipError_t oe =
-        plan.hybrid ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, render_f32_kernel<true>, plan.block, plan.lds_bytes)
-                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, render_f32_kernel<false>, plan.block, 0);
+    const hipError_t oe = plan.scan == DRAY_SCAN_HYBRID ? occupancy_of<kScanHybrid>(&occ, plan.block, plan.lds_bytes)
+                          : plan.scan == DRAY_SCAN_GRID ? occupancy_of<kScanGrid>(&occ, plan.block, 0)
+                                                        : occupancy_of<kScanScalar>(&occ, plan.block, 0);
     if (oe == hipSuccess && occ > 0) per_cu = occ;
     plan.grid = cus * per_cu;
     const long long npix = (long long)part.n_rows * cam.W;
@@ -519,16 +690,24 @@ hipError_t launch_render_f32(const CamDev<float>& cam, const SceneDev& scene, co
     if (npix > 0x7fffffffLL / 3) return hipErrorInvalidValue; // the kernel indexes the three sum planes with 32 bits
     if (cam.spp > 0xFFFFFF) return hipErrorInvalidValue;     // a lane keeps its sample index in 24 bits
     const F32Tables& t = scene.f32;
-    if (plan.hybrid)
-        hipLaunchKernelGGL(render_f32_kernel<true>, dim3(plan.grid), dim3(plan.block), plan.lds_bytes, stream, cam,
-                           t.narrow_geom, t.filter_xy, t.filter_zn, t.narrow_index, t.wide_index, t.geom64, t.geom32,
-                           t.mat32, t.kind, t.n_narrow_padded, t.n_wide, part, key, plan.pixels_per_pool, d_accum,
-                           d_counters);
+    F32Args args{};
+    args.cam = cam;
+    args.narrow_geom = (const V4*)t.narrow_geom; args.filter_xy = (const V4*)t.filter_xy; args.filter_zn = (const V4*)t.filter_zn;
+    args.narrow_index = t.narrow_index; args.wide_index = t.wide_index;
+    args.geom64 = t.geom64; args.geom32 = (const V4*)t.geom32; args.mat32 = (const V4*)t.mat32; args.kind = t.kind;
+    args.n_narrow_padded = t.n_narrow_padded; args.n_wide = t.n_wide;
+    args.grid = scene.grid;
+    args.part = part; args.key = key; args.pixels_per_pool = plan.pixels_per_pool;
+    args.accum = d_accum; args.counters = d_counters;
+    auto launch = [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, dim3(plan.grid), dim3(plan.block), plan.lds_bytes, stream, args);
+    };
+    if (plan.scan == DRAY_SCAN_HYBRID)
+        launch(render_f32_kernel<kScanHybrid>);
+    else if (plan.scan == DRAY_SCAN_GRID)
+        launch(render_f32_kernel<kScanGrid>);
     else
-        hipLaunchKernelGGL(render_f32_kernel<false>, dim3(plan.grid), dim3(plan.block), 0, stream, cam, t.narrow_geom,
-                           t.filter_xy, t.filter_zn, t.narrow_index, t.wide_index, t.geom64, t.geom32, t.mat32, t.kind,
-                           t.n_narrow_padded, t.n_wide, part, key, plan.pixels_per_pool, d_accum,
-                           d_counters);
+        launch(render_f32_kernel<kScanScalar>);
     return hipGetLastError();
 }
 

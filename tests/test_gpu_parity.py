@@ -178,7 +178,7 @@ def test_f32_scan_variants_agree(dray, gpu):
     cam.mode = dray.MODE_F32
     for spheres in (dray.scene_final(1), dray.scene_final(7), dray.scene_three_spheres()):
         a = render_gpu(dray, gpu, spheres, cam, seed=13, variant=dray.SCAN_SCALAR)
-        for v in (dray.SCAN_HYBRID, dray.SCAN_AUTO):
+        for v in (dray.SCAN_HYBRID, dray.SCAN_GRID, dray.SCAN_AUTO):
             b = render_gpu(dray, gpu, spheres, cam, seed=13, variant=v)
             assert (a[0] == b[0]).all() and (a[1] == b[1]).all() and a[3].segments == b[3].segments, v
     # a camera far from the origin: large |o| stresses the filter's slack (its error grows with |o|^2 + |c|^2)
@@ -188,10 +188,58 @@ def test_f32_scan_variants_agree(dray, gpu):
     far.focus_dist, far.defocus_angle = 100.0, 0.0
     spheres = dray.scene_final(1)
     a = render_gpu(dray, gpu, spheres, far, seed=5, variant=dray.SCAN_SCALAR)
-    b = render_gpu(dray, gpu, spheres, far, seed=5, variant=dray.SCAN_HYBRID)
-    assert (a[0] == b[0]).all() and (a[1] == b[1]).all() and a[3].segments == b[3].segments
+    for v in (dray.SCAN_HYBRID, dray.SCAN_GRID):
+        b = render_gpu(dray, gpu, spheres, far, seed=5, variant=v)
+        assert (a[0] == b[0]).all() and (a[1] == b[1]).all() and a[3].segments == b[3].segments
     with pytest.raises(dray.DrayError):
         render_gpu(dray, gpu, spheres, cam, seed=13, variant=9)
+
+
+def soup(rng, n, box, r_lo, r_hi, extra=()):
+    """Random overlapping spheres of every material in [-box, box]^3, plus `extra` (centre, radius) spheres."""
+    sp = np.zeros(n + len(extra), dtype=np.dtype(
+        [("center", "<f8", 3), ("radius", "<f8"), ("kind", "<u4"), ("_pad", "<u4"), ("albedo", "<f8", 3),
+         ("fuzz_or_ior", "<f8")]))
+    sp["center"][:n] = rng.uniform(-box, box, size=(n, 3))
+    sp["radius"][:n] = rng.uniform(r_lo, r_hi, size=n)
+    for k, (c, r) in enumerate(extra):
+        sp["center"][n + k] = c
+        sp["radius"][n + k] = r
+    sp["kind"] = rng.integers(0, 4, size=len(sp))
+    sp["albedo"] = rng.uniform(0.2, 1.0, size=(len(sp), 3))
+    sp["fuzz_or_ior"] = np.where(sp["kind"] == 3, 1.5, rng.uniform(0.0, 0.6, size=len(sp)))
+    return sp[rng.permutation(len(sp))]
+
+
+def test_f32_grid_scan_equals_scalar_scan_on_random_scenes(dray, gpu):
+    """The grid walk must return the scalar scan's closest hit, ties and all: overlapping spheres of mixed size,
+    a camera inside the cloud (paths start and scatter inside spheres), spheres too large for the grid (kept in the
+    loose list), a ground sphere routed to the f64 test, exact duplicates (equal-t ties), a flat and a deep layout."""
+    rng = np.random.default_rng(77)
+    dup = [((0.3, 0.1, -0.2), 0.7), ((0.3, 0.1, -0.2), 0.7), ((0.3, 0.1, -0.2), 0.7)]
+    scenes = {
+        "soup": soup(rng, 300, 5.0, 0.05, 1.5, extra=dup + [((0.0, -1040.0, 0.0), 1000.0), ((2.0, 3.0, 1.0), 6.0)]),
+        "dust": soup(rng, 3000, 8.0, 0.01, 0.12, extra=[((0.0, 0.0, 0.0), 20.0)]),
+        "flat": soup(rng, 500, 30.0, 0.1, 0.5) ,
+        "pair": soup(rng, 2, 1.0, 0.2, 0.4),
+    }
+    scenes["flat"]["center"][:, 1] *= 0.01
+    for name, spheres in scenes.items():
+        for lookfrom, vfov in (((0.5, 0.4, 0.3), 90.0), ((40.0, 9.0, 25.0), 25.0)):
+            cam = dray.camera_final(width=80, spp=6, depth=30)
+            cam.mode = dray.MODE_F32
+            cam.lookfrom, cam.lookat, cam.vfov, cam.defocus_angle = lookfrom, (0.0, 0.0, 0.0), vfov, 0.0
+            a = render_gpu(dray, gpu, spheres, cam, seed=19, variant=dray.SCAN_SCALAR)
+            b = render_gpu(dray, gpu, spheres, cam, seed=19, variant=dray.SCAN_GRID)
+            same = (a[0] == b[0]).all() and (a[1] == b[1]).all() and a[3].segments == b[3].segments
+            assert same, (name, lookfrom, int((a[0] != b[0]).sum()), a[3].segments, b[3].segments)
+    # an axis-parallel bundle: zero direction components take the walk's parallel-ray branch
+    cam = dray.camera_final(width=33, spp=2, depth=8)
+    cam.mode = dray.MODE_F32
+    cam.lookfrom, cam.lookat, cam.vfov, cam.defocus_angle = (0.0, 0.0, 30.0), (0.0, 0.0, 0.0), 1e-4, 0.0
+    a = render_gpu(dray, gpu, scenes["soup"], cam, seed=3, variant=dray.SCAN_SCALAR)
+    b = render_gpu(dray, gpu, scenes["soup"], cam, seed=3, variant=dray.SCAN_GRID)
+    assert (a[0] == b[0]).all() and (a[1] == b[1]).all() and a[3].segments == b[3].segments
 
 
 def test_f32_close_to_oracle(dray, gpu, oracle):
