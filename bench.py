@@ -74,7 +74,7 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--mode", default="f32", choices=["f32", "f64", "f32plain"])
     ap.add_argument("--pixels-per-pool", type=int, default=0)
-    ap.add_argument("--variant", type=int, default=0, help="f32 sphere-scan formulation: 0 auto, 1 scalar, 2 hybrid (identical images)")
+    ap.add_argument("--variant", type=int, default=0, help="f32 sphere-scan formulation: 0 auto, 1 scalar, 2 hybrid, 3 grid (identical images)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -167,13 +167,31 @@ def main():
                 "frac": achieved / PEAK_FP32_VALU,
                 "traffic": measured_traffic(args, world),
                 "traffic_unit": "bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE, separate PMC passes of this command)",
-                "kernel": "render_f32_kernel" if args.mode == "f32" else "render_ref_kernel",
+                "kernel": ("render_f32_kernel (%s scan)" % {0: "grid", 1: "scalar", 2: "hybrid", 3: "grid"}[args.variant]) if args.mode == "f32" else "render_ref_kernel",
                 "kernel_ms": k_s * 1e3,
                 "resolve_ms": resolve_ms / max(args.steps, 1),
-                "note": "algorithmic FLOP = 18 x spheres x segments of one launch (rank 0), over the launch's "
-                        "HIP-event duration; FP32 vector peak 157.3 TFLOP/s",
+                "note": "algorithmic FLOP = 18 x spheres x segments of one launch (rank 0), the work of the "
+                        "reference's linear sphere scan, over the launch's HIP-event duration; FP32 vector peak "
+                        "157.3 TFLOP/s.  The default scan walks a uniform grid and skips most of those tests (same "
+                        "image), so this reference-equivalent rate can exceed the peak; roofline_bruteforce is the "
+                        "kernel that executes every test",
             },
         }
+        if args.mode == "f32" and args.variant in (0, 3):
+            # the same frame through the scan that performs all 18 x spheres x segments flops (identical image)
+            brute = partition.DistributedRenderer(
+                cam, partition.gpu_render_rows(scene, pixels_per_pool=args.pixels_per_pool, variant=d.SCAN_HYBRID
+                                               if n_spheres <= 8192 else d.SCAN_SCALAR),
+                partition.gpu_alloc(local_rank), rank=rank, world_size=world) if world == 1 else None
+            if brute is not None:
+                brute.step()
+                _, bst = brute.step()
+                b_s = bst.kernel_ms / 1e3
+                b_ach = FLOP_PER_TEST * n_spheres * bst.segments / b_s if b_s > 0 else 0.0
+                out["roofline_bruteforce"] = {
+                    "bound": "valu", "achieved": b_ach / 1e12, "peak": PEAK_FP32_VALU / 1e12, "unit": "TFLOP/s",
+                    "frac": b_ach / PEAK_FP32_VALU, "kernel": "render_f32_kernel (hybrid scan)",
+                    "kernel_ms": bst.kernel_ms, "mrays_s": bst.segments / b_s / 1e6 if b_s > 0 else 0.0}
         if world == 1 and not args.no_cpu_baseline:
             one, many = cpu_baseline(spheres, args.width, args.depth, args.seed)
             out["cpu_baseline"] = one

@@ -108,6 +108,7 @@ class Stats(C.Structure):
         ("rows_rendered", C.c_int32),
         ("n_spheres", C.c_int32),
         ("n_wide_spheres", C.c_int32),
+        ("walk_steps", C.c_uint64),
     ]
 
 

@@ -8,6 +8,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -185,7 +186,13 @@ void build_grid(const std::vector<float>& ng, int32_t n_narrow, GridHost& g) {
         hi[a] += pad;
         ext[a] = hi[a] - lo[a];
     }
-    double target = 4.0 * n_narrow; // cells aimed at
+    // cells aimed at per sphere; DRAY_GRID_CELLS_PER_SPHERE overrides the default for tuning runs
+    double density = 2.0; // measured on the 485-sphere frame: 0.5 -> 28.1 ms, 1 -> 23.1, 2 -> 22.0, 4 -> 23.2, 8 -> 24.9 (200 spp)
+    if (const char* env = std::getenv("DRAY_GRID_CELLS_PER_SPHERE")) {
+        const double v = std::atof(env);
+        if (v > 0.01 && v < 1000.) density = v;
+    }
+    double target = density * n_narrow;
     for (int attempt = 0;; ++attempt) {
         int32_t n[3];
         const double scale = std::cbrt(target / (ext[0] * ext[1] * ext[2]));
@@ -468,6 +475,7 @@ int render_device_impl(const dray_camera* cam, dray_scene* scene, uint32_t* d_co
         HIP_TRY(hipEventElapsedTime(&k_ms, scene->ev[0], scene->ev[1]));
         HIP_TRY(hipEventElapsedTime(&r_ms, scene->ev[1], scene->ev[2]));
         stats->segments = hc.segments;
+        stats->walk_steps = hc.walk_steps;
         stats->samples = (opts.mode == DRAY_MODE_F32 && cam->max_depth <= 0)
                              ? (uint64_t)part.n_rows * (uint64_t)W * (uint64_t)cam->samples_per_pixel
                              : hc.samples;

@@ -93,7 +93,7 @@ struct DeviceCounters {
     unsigned long long segments;
     unsigned long long samples;
     unsigned long long next_item; // work queue head of the throughput kernel
-    unsigned long long _pad;
+    unsigned long long walk_steps; // grid scan: wave-level steps
 };
 
 // render_ref.hip

@@ -37,10 +37,18 @@ constexpr int kPoolSamples = 64;               // samples a wave aims to take fr
 constexpr float kSlack = 7.62939453125e-6f;   // 2^-17, see scan_hybrid
 constexpr int kSlots = 32;                     // pixel sums a wave keeps in LDS before they go to memory
 constexpr uint32_t kNoPixel = 0xFFFFFFFFu;
+#ifndef DRAY_WALK_QUORUM
+#define DRAY_WALK_QUORUM 16
+#endif
+constexpr int kWalkQuorum = DRAY_WALK_QUORUM;     // grid scan: lanes that must still be walking for the wave to keep stepping
 
 // Waves per SIMD the register allocation of the trace kernel aims at (7 = at most 72 VGPRs; measured fastest: 6 -> 100.6 ms, 7 -> 96.4 ms, 8 -> 102.6 ms per 1200x675x500 frame).
 #ifndef DRAY_WAVES_PER_EU
 #define DRAY_WAVES_PER_EU 7
+#endif
+// The grid kernel keeps a lane's walk alive across the main loop and wants more registers per lane.
+#ifndef DRAY_GRID_WAVES_PER_EU
+#define DRAY_GRID_WAVES_PER_EU 6
 #endif
 
 // Pointer into the constant address space: a wave-uniform read through it is a scalar load that the compiler
@@ -230,79 +238,99 @@ __device__ __forceinline__ void exact_test_unordered(ScanBest& b, const V s, con
 //   * the walk stops only when the best root is before the cell's exit by more than the exit's rounding error;
 //   * boundary times are recomputed from the integer cell index each step, never accumulated.
 // Spheres spanning too many cells are kept in a short list every ray tests first.
-__device__ __forceinline__ void scan_grid(ConstPtr<GridDev> gp, ConstPtr<V4> narrow_geom, const PathRay& ray,
-                                          ScanBest& b) {
+// A lane's walk survives the kernel's main loop: lanes whose walk is over are shaded and given their next ray
+// while the long walks of other lanes go on, instead of the whole wave waiting for its longest walk.
+struct Walk {
+    float A[3], B[3]; // time at which the ray reaches plane k of an axis: fma(k, A, B)
+    float slack;      // bound on the rounding error of those times
+    int32_t c[3];     // current cell
+    uint32_t ahead;   // bit a: the ray moves towards larger indices on axis a
+    uint32_t e, e_end; // entries of the current cell still to test
+};
+
+// Tests the loose spheres, then places the ray in its first cell.  Returns false when there is nothing to walk.
+__device__ __forceinline__ bool walk_begin(ConstPtr<GridDev> gp, ConstPtr<V4> narrow_geom, const PathRay& ray,
+                                           ScanBest& b, Walk& w) {
     const DRAY_CONSTANT GridDev& g = *gp;
     for (int32_t k = 0; k < g.n_loose; ++k) { // wave-uniform
         const int32_t pos = g.loose[k];
         exact_test_unordered(b, narrow_geom[pos], ray, pos);
     }
-    if (g.n[0] == 0) return;
+    if (g.n[0] == 0) return false;
     const float o[3] = {ray.o.x, ray.o.y, ray.o.z}, d[3] = {ray.d.x, ray.d.y, ray.d.z};
-    float A[3], B[3]; // time at which the ray reaches plane k of an axis: fma(k, A, B)
-    int32_t ahead[3]; // 1 when the ray moves towards larger indices on the axis
     float t_in = 0.f, t_out = INFINITY, bmax = 0.f;
+    w.ahead = 0u;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-        ahead[a] = d[a] >= 0.f ? 1 : 0;
+        if (d[a] >= 0.f) w.ahead |= 1u << a;
         if (fabsf(d[a]) > 1e-12f) {
             const float inv = rcp(d[a]);
-            A[a] = g.cell[a] * inv;
-            B[a] = (g.lo[a] - o[a]) * inv;
-            const float t0 = B[a], t1 = (g.hi[a] - o[a]) * inv;
+            w.A[a] = g.cell[a] * inv;
+            w.B[a] = (g.lo[a] - o[a]) * inv;
+            const float t0 = w.B[a], t1 = (g.hi[a] - o[a]) * inv;
             t_in = fmaxf(t_in, fminf(t0, t1));
             t_out = fminf(t_out, fmaxf(t0, t1));
-            bmax = fmaxf(bmax, fabsf(B[a]));
+            bmax = fmaxf(bmax, fabsf(w.B[a]));
         } else { // parallel to the axis' planes: never crosses one; misses the grid if outside its slab
-            A[a] = 0.f;
-            B[a] = INFINITY;
+            w.A[a] = 0.f;
+            w.B[a] = INFINITY;
             if (o[a] < g.lo[a] || o[a] > g.hi[a]) t_out = -INFINITY;
         }
     }
-    const float slack = bmax * 3.814697265625e-6f; // 2^-18 of the largest term the boundary times are formed from
-    bool walking = t_in <= t_out + slack;
-    int32_t c[3];
+    w.slack = bmax * 3.814697265625e-6f; // 2^-18 of the largest term the boundary times are formed from
+    const bool walking = t_in <= t_out + w.slack;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         const float at = (fmaf(d[a], t_in, o[a]) - g.lo[a]) * g.inv_cell[a];
-        c[a] = min(max((int32_t)floorf(at), 0), g.n[a] - 1);
+        w.c[a] = min(max((int32_t)floorf(at), 0), g.n[a] - 1);
     }
-    uint32_t e = 0u, e_end = 0u;
+    w.e = w.e_end = 0u;
     if (walking) {
-        const uint2 rec = g.cells[(c[2] * g.n[1] + c[1]) * g.n[0] + c[0]];
-        e = rec.x;
-        e_end = rec.x + rec.y;
+        const uint2 rec = g.cells[(w.c[2] * g.n[1] + w.c[1]) * g.n[0] + w.c[0]];
+        w.e = rec.x;
+        w.e_end = rec.x + rec.y;
     }
-    while (__ballot(walking) != 0ull) {
-        if (walking) {
-            if (e == e_end) { // this cell is done: stop, or step into the next one
-                const float tx = fmaf((float)(c[0] + ahead[0]), A[0], B[0]);
-                const float ty = fmaf((float)(c[1] + ahead[1]), A[1], B[1]);
-                const float tz = fmaf((float)(c[2] + ahead[2]), A[2], B[2]);
-                const float t_exit = fminf(tx, fminf(ty, tz));
-                if (b.t < fmaf(t_exit, 1.f - 3.814697265625e-6f, -slack)) {
-                    walking = false;
-                } else {
-                    const int axis = (tx <= ty && tx <= tz) ? 0 : (ty <= tz ? 1 : 2);
-                    if (axis == 0) c[0] += ahead[0] ? 1 : -1;
-                    if (axis == 1) c[1] += ahead[1] ? 1 : -1;
-                    if (axis == 2) c[2] += ahead[2] ? 1 : -1;
-                    if ((uint32_t)c[0] >= (uint32_t)g.n[0] || (uint32_t)c[1] >= (uint32_t)g.n[1] ||
-                        (uint32_t)c[2] >= (uint32_t)g.n[2]) {
-                        walking = false;
-                    } else {
-                        const uint2 rec = g.cells[(c[2] * g.n[1] + c[1]) * g.n[0] + c[0]];
-                        e = rec.x;
-                        e_end = rec.x + rec.y;
-                    }
-                }
-            }
-            if (walking && e != e_end) {
-                exact_test_unordered(b, g.entry_geom[e], ray, g.entry_pos[e]);
-                ++e;
-            }
-        }
+    return walking;
+}
+
+// What a step reads of the grid, held in scalar registers while a wave is stepping.
+struct GridRegs {
+    int32_t n0, n1, n2;
+    const uint2* cells;
+    const V4* entry_geom;
+    const int32_t* entry_pos;
+};
+
+// One step of a walking lane: leave a finished cell (or stop), then test one listed sphere.  Returns false when
+// the walk is over.  Written with selects instead of nested branches: the lanes of a wave rarely agree here.
+__device__ __forceinline__ bool walk_step(const GridRegs& g, const PathRay& ray, ScanBest& b, Walk& w) {
+    bool go = true;
+    if (w.e == w.e_end) { // this cell is done: stop, or step into the next one
+        const int32_t ax = (int32_t)(w.ahead & 1u), ay = (int32_t)((w.ahead >> 1) & 1u), az = (int32_t)((w.ahead >> 2) & 1u);
+        const float tx = fmaf((float)(w.c[0] + ax), w.A[0], w.B[0]);
+        const float ty = fmaf((float)(w.c[1] + ay), w.A[1], w.B[1]);
+        const float tz = fmaf((float)(w.c[2] + az), w.A[2], w.B[2]);
+        const float t_exit = fminf(tx, fminf(ty, tz));
+        const bool stop = b.t < fmaf(t_exit, 1.f - 3.814697265625e-6f, -w.slack);
+        const bool sx = tx <= ty && tx <= tz;
+        const bool sy = !sx && ty <= tz;
+        w.c[0] += sx ? 2 * ax - 1 : 0;
+        w.c[1] += sy ? 2 * ay - 1 : 0;
+        w.c[2] += (sx || sy) ? 0 : 2 * az - 1;
+        const bool inside = (uint32_t)w.c[0] < (uint32_t)g.n0 && (uint32_t)w.c[1] < (uint32_t)g.n1 &&
+                            (uint32_t)w.c[2] < (uint32_t)g.n2;
+        go = inside && !stop;
+        // cell counts are at most 256 per axis: 24-bit multiplies (full rate) are exact
+        const int32_t ci = go ? __mul24(__mul24(w.c[2], g.n1) + w.c[1], g.n0) + w.c[0] : 0;
+        const uint2 rec = g.cells[ci];
+        w.e = rec.x;
+        w.e_end = go ? rec.x + rec.y : rec.x;
     }
+    if (w.e != w.e_end) {
+        exact_test_unordered(b, g.entry_geom[w.e], ray, g.entry_pos[w.e]);
+        ++w.e;
+    }
+    return go;
 }
 
 // Everything a launch of the trace kernel is given.
@@ -335,13 +363,11 @@ __device__ __forceinline__ ConstPtr<T> opaque(ConstPtr<T> p) {
 }
 
 template <int SCAN>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DRAY_WAVES_PER_EU, DRAY_WAVES_PER_EU))) void render_f32_kernel(
-    F32Args args_in_kernarg_segment) {
+__device__ __forceinline__ void render_f32_body() {
     // The arguments (some sixty scalar registers' worth) are read where they are used, straight from the kernel
     // argument segment, and the pointer to it is made opaque once per path segment.  Left to itself the compiler
     // loads them all above the main loop, runs out of scalar registers and spills inside the sphere scan -- where a
     // change anywhere else in the kernel then decides how many reloads the scan carries.
-    (void)args_in_kernarg_segment;
     ConstPtr<F32Args> a = (ConstPtr<F32Args>)__builtin_amdgcn_kernarg_segment_ptr();
     const int lane = __lane_id();
     extern __shared__ V4 lds_xy[]; // hybrid scan: cx, cy of two consecutive narrow spheres per entry
@@ -403,10 +429,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DRAY_WAVES_
     uint32_t n_seg = 0;
     PathRay ray = {{0.f, 0.f, 0.f}, {0.f, 0.f, 1.f}, 0.001f};
     F3 thr = {1.f, 1.f, 1.f};
+    bool fresh = false;   // the ray has not been intersected yet
+    bool walking = false; // grid scan: the lane is on its way through the grid
+    ScanBest sb = {INFINITY, -1, false};
+    Walk walk = {};
     // wave-uniform queue state
     uint32_t pool_pix = 0u, pool_q = 0u, pool_n = 0u; // first pixel, next sample, sample count of the pool
     uint32_t pool_slot = 0u, pool_pixels = 0u;         // cache slot of the pool's first pixel, pixels in the pool
     unsigned long long n_samples = 0ull;               // samples of the pools this wave has opened
+    uint32_t n_steps = 0u;                             // grid scan: steps this wave has taken
     bool exhausted = false;
 
     for (;;) {
@@ -455,6 +486,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DRAY_WAVES_
                 camera_ray(&a->cam, pi, pj, st, ray);
                 thr = {1.f, 1.f, 1.f};
                 stage = 1;
+                fresh = true;
                 need = false;
             }
             pool_q += take;
@@ -462,18 +494,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DRAY_WAVES_
         }
         if (__ballot(stage > 0) == 0ull) break;
 
-        if (stage > 0) {
+        // ---- closest hit over the sphere list: hittable_list.rs:60-74 ---------------------------
+        if (fresh) {
             n_seg++;
-            // ---- closest hit over the sphere list: hittable_list.rs:60-74 -----------------------
-            const float ox = ray.o.x, oy = ray.o.y, oz = ray.o.z, dx = ray.d.x, dy = ray.d.y, dz = ray.d.z;
-            const float tmin = ray.tmin;
-            ScanBest sb = {INFINITY, -1, false};
+            sb = {INFINITY, -1, false};
             if constexpr (SCAN == kScanHybrid)
                 scan_hybrid(lds_xy, as_constant(a->filter_zn), as_constant(a->narrow_geom), a->n_narrow_padded, ray, sb);
             else if constexpr (SCAN == kScanGrid)
-                scan_grid(&a->grid, as_constant(a->narrow_geom), ray, sb);
+                walking = walk_begin(&a->grid, as_constant(a->narrow_geom), ray, sb, walk);
             else
                 scan_scalar(as_constant(a->narrow_geom), a->n_narrow_padded, ray, sb);
+            fresh = false;
+        }
+        if constexpr (SCAN == kScanGrid) {
+            // walk until fewer than a quorum of lanes are still on their way (all of them once the queue is empty)
+            const int quorum = exhausted ? 1 : kWalkQuorum;
+            const GridRegs gr = {a->grid.n[0], a->grid.n[1], a->grid.n[2], a->grid.cells,
+                                 (const V4*)a->grid.entry_geom, a->grid.entry_pos};
+            do {
+                if (walking) walking = walk_step(gr, ray, sb, walk);
+                ++n_steps;
+            } while (__popcll(__ballot(walking)) >= quorum);
+        }
+
+        if (stage > 0 && !walking) {
+            const float ox = ray.o.x, oy = ray.o.y, oz = ray.o.z, dx = ray.d.x, dy = ray.d.y, dz = ray.d.z;
+            const float tmin = ray.tmin;
             float best = sb.t;
             // Re-evaluate the winner from the perpendicular remainder |oc - h d|, which does not cancel.
             int32_t bidx = -1; // position in the caller's list
@@ -586,6 +632,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DRAY_WAVES_
                     if (stage <= a->cam.max_depth) { // camera.rs:265: the next call would still have depth > 0
                         ray.o = hp;
                         set_dir(ray, nd);
+                        fresh = true;
                         ended = false;
                     }
                 }
@@ -615,7 +662,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DRAY_WAVES_
     if (lane == 0) {
         atomicAdd(&a->counters->segments, segs);
         atomicAdd(&a->counters->samples, n_samples);
+        if constexpr (SCAN == kScanGrid) atomicAdd(&a->counters->walk_steps, (unsigned long long)n_steps);
     }
+}
+
+// The three kernels differ in the sphere scan and in the register budget that suits it.  The argument block is
+// only ever read through the kernel-argument segment pointer (see render_f32_body).
+template <int SCAN>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DRAY_WAVES_PER_EU, DRAY_WAVES_PER_EU))) void render_f32_kernel(
+    F32Args) {
+    render_f32_body<SCAN>();
+}
+template <>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DRAY_GRID_WAVES_PER_EU, DRAY_GRID_WAVES_PER_EU))) void render_f32_kernel<kScanGrid>(
+    F32Args) {
+    render_f32_body<kScanGrid>();
 }
 
 // Adds the fixed-point sums into the caller's buffers and writes the packed colour: colors.rs:38-43.

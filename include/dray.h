@@ -136,6 +136,8 @@ typedef struct dray_stats {
     int32_t rows_rendered;
     int32_t n_spheres;
     int32_t n_wide_spheres; /* spheres routed to the f64 intersection in DRAY_MODE_F32 */
+    uint64_t walk_steps;    /* grid scan: steps summed over waves (a step moves every walking lane of a wave on by
+                               one cell or one sphere); 0 for the other scans */
 } dray_stats;
 
 typedef struct dray_scene dray_scene; /* device-resident sphere tables + workspace */

@@ -30,7 +30,7 @@ def test_struct_layouts_match_header(dray):
     from dray_amd import _ffi
     assert C.sizeof(_ffi.CameraPOD) == C.sizeof(O.Camera) == 8 + 16 + 8 + 72 + 16
     assert C.sizeof(_ffi.SpherePOD) == C.sizeof(O.Sphere) == 72
-    assert C.sizeof(_ffi.Opts) == 40 and C.sizeof(_ffi.Stats) == 56
+    assert C.sizeof(_ffi.Opts) == 40 and C.sizeof(_ffi.Stats) == 64
     o = _ffi.default_opts()
     assert (o.seed, o.mode, o.flags, o.sample_offset, o.device, o.row_begin, o.row_step) == (1, 1, 0, 0, -1, 0, 1)
 

@@ -44,13 +44,14 @@ def main():
             st = ddev.render_device(cam, scene, color, raw, count, variant=a[0], pixels_per_pool=a[1])
             times[a].append(st.kernel_ms)
             segs[a] = st.segments
+            steps = st.walk_steps
     for a in arms:
         med, mn = statistics.median(times[a]), min(times[a])
         tf = 18.0 * len(spheres) * segs[a] / (med * 1e-3) / 1e12
         print(json.dumps({"tag": args.tag, "lib": os.environ.get("DRAY_HIP_LIB", "in-tree"), "variant": a[0],
                           "pixels_per_pool": a[1], "median_ms": round(med, 3), "min_ms": round(mn, 3),
                           "mrays_s": round(segs[a] / med / 1e3, 1), "algo_tflops": round(tf, 2),
-                          "frac_of_157.3": round(tf / 157.3, 4)}))
+                          "frac_of_157.3": round(tf / 157.3, 4), "walk_steps": int(steps)}))
     scene.close()
 
 
