@@ -48,7 +48,7 @@ constexpr int kWalkQuorum = DRAY_WALK_QUORUM;     // grid scan: lanes that must 
 #endif
 // The grid kernel keeps a lane's walk alive across the main loop and wants more registers per lane.
 #ifndef DRAY_GRID_WAVES_PER_EU
-#define DRAY_GRID_WAVES_PER_EU 6
+#define DRAY_GRID_WAVES_PER_EU 5
 #endif
 
 // Pointer into the constant address space: a wave-uniform read through it is a scalar load that the compiler
@@ -207,27 +207,6 @@ __device__ __forceinline__ void scan_hybrid(const V4* lds_xy, ConstPtr<V4> filte
 
 constexpr int kScanScalar = DRAY_SCAN_SCALAR, kScanHybrid = DRAY_SCAN_HYBRID, kScanGrid = DRAY_SCAN_GRID;
 
-// The exact test for a scan that does not visit the spheres in insertion order: on equal t the sphere inserted
-// earlier wins explicitly (hittable_list.rs:65-70 keeps the first of equals).
-template <typename V>
-__device__ __forceinline__ void exact_test_unordered(ScanBest& b, const V s, const PathRay& ray, int32_t pos) {
-    const float ocx = s.x - ray.o.x, ocy = s.y - ray.o.y, ocz = s.z - ray.o.z;
-    const float h = fmaf(ocz, ray.d.z, fmaf(ocy, ray.d.y, ocx * ray.d.x));
-    const float q = fmaf(-ocz, ocz, fmaf(-ocy, ocy, fmaf(-ocx, ocx, s.w)));
-    const float disc = fmaf(h, h, q);
-    if (disc >= 0.f) {
-        const float sq = fsqrt(disc);
-        const float t0 = h - sq;
-        const bool far = !(t0 > ray.tmin);
-        const float t = far ? h + sq : t0;
-        if (t > ray.tmin && (t < b.t || (t == b.t && pos < b.pos))) {
-            b.t = t;
-            b.pos = pos;
-            b.far = far;
-        }
-    }
-}
-
 // Grid scan: every lane walks its own ray through the uniform grid (3-D DDA) and applies the exact test to the
 // spheres listed in the cells it crosses, front to back, until the closest accepted root lies before the exit of
 // the current cell.  The result is the minimum over (t, insertion position) of the accepted roots, which is what
@@ -244,17 +223,41 @@ struct Walk {
     float A[3], B[3]; // time at which the ray reaches plane k of an axis: fma(k, A, B)
     float slack;      // bound on the rounding error of those times
     int32_t c[3];     // current cell
+    uint32_t ci;      // its index in the cell table
     uint32_t ahead;   // bit a: the ray moves towards larger indices on axis a
     uint32_t e, e_end; // entries of the current cell still to test
+    // Closest accepted root so far as one ordered key: bits of t (positive floats order like integers) in the high
+    // word, then the sphere's narrow position and the far-root flag.  The minimum key is the scalar scan's answer:
+    // smallest t, on equal t the sphere inserted first (hittable_list.rs:65-70).
+    unsigned long long best;
 };
 
+constexpr unsigned long long kNoHit = 0x7F800000FFFFFFFFull; // t = +inf
+
+__device__ __forceinline__ void walk_test(Walk& w, const V4 s, int32_t pos, const PathRay& ray) {
+    // exact_test without branches: in a walked cell a test succeeds often enough that some lane of the wave nearly
+    // always takes them, and every level of branching costs mask bookkeeping on the scalar unit
+    const float ocx = s.x - ray.o.x, ocy = s.y - ray.o.y, ocz = s.z - ray.o.z;
+    const float h = fmaf(ocz, ray.d.z, fmaf(ocy, ray.d.y, ocx * ray.d.x));
+    const float q = fmaf(-ocz, ocz, fmaf(-ocy, ocy, fmaf(-ocx, ocx, s.w)));
+    const float disc = fmaf(h, h, q);
+    const float sq = fsqrt(fmaxf(disc, 0.f));
+    const float t0 = h - sq;
+    const bool far = !(t0 > ray.tmin);
+    const float t = far ? h + sq : t0;
+    const bool valid = (disc >= 0.f) & (t > ray.tmin); // t > tmin > 0: its bits order like an unsigned integer
+    const unsigned long long key =
+        ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)(((uint32_t)pos << 1) | (far ? 1u : 0u));
+    w.best = (valid & (key < w.best)) ? key : w.best;
+}
+
 // Tests the loose spheres, then places the ray in its first cell.  Returns false when there is nothing to walk.
-__device__ __forceinline__ bool walk_begin(ConstPtr<GridDev> gp, ConstPtr<V4> narrow_geom, const PathRay& ray,
-                                           ScanBest& b, Walk& w) {
+__device__ __forceinline__ bool walk_begin(ConstPtr<GridDev> gp, ConstPtr<V4> narrow_geom, const PathRay& ray, Walk& w) {
     const DRAY_CONSTANT GridDev& g = *gp;
+    w.best = kNoHit;
     for (int32_t k = 0; k < g.n_loose; ++k) { // wave-uniform
         const int32_t pos = g.loose[k];
-        exact_test_unordered(b, narrow_geom[pos], ray, pos);
+        walk_test(w, narrow_geom[pos], pos, ray);
     }
     if (g.n[0] == 0) return false;
     const float o[3] = {ray.o.x, ray.o.y, ray.o.z}, d[3] = {ray.d.x, ray.d.y, ray.d.z};
@@ -285,8 +288,9 @@ __device__ __forceinline__ bool walk_begin(ConstPtr<GridDev> gp, ConstPtr<V4> na
         w.c[a] = min(max((int32_t)floorf(at), 0), g.n[a] - 1);
     }
     w.e = w.e_end = 0u;
+    w.ci = (uint32_t)((w.c[2] * g.n[1] + w.c[1]) * g.n[0] + w.c[0]);
     if (walking) {
-        const uint2 rec = g.cells[(w.c[2] * g.n[1] + w.c[1]) * g.n[0] + w.c[0]];
+        const uint2 rec = g.cells[w.ci];
         w.e = rec.x;
         w.e_end = rec.x + rec.y;
     }
@@ -295,15 +299,16 @@ __device__ __forceinline__ bool walk_begin(ConstPtr<GridDev> gp, ConstPtr<V4> na
 
 // What a step reads of the grid, held in scalar registers while a wave is stepping.
 struct GridRegs {
-    int32_t n0, n1, n2;
+    int32_t n0, n1, n2, n01;
     const uint2* cells;
     const V4* entry_geom;
     const int32_t* entry_pos;
 };
 
 // One step of a walking lane: leave a finished cell (or stop), then test one listed sphere.  Returns false when
-// the walk is over.  Written with selects instead of nested branches: the lanes of a wave rarely agree here.
-__device__ __forceinline__ bool walk_step(const GridRegs& g, const PathRay& ray, ScanBest& b, Walk& w) {
+// the walk is over.  Written with selects and bitwise conditions instead of nested branches: the lanes of a wave
+// rarely agree here.
+__device__ __forceinline__ bool walk_step(const GridRegs& g, const PathRay& ray, Walk& w) {
     bool go = true;
     if (w.e == w.e_end) { // this cell is done: stop, or step into the next one
         const int32_t ax = (int32_t)(w.ahead & 1u), ay = (int32_t)((w.ahead >> 1) & 1u), az = (int32_t)((w.ahead >> 2) & 1u);
@@ -311,23 +316,22 @@ __device__ __forceinline__ bool walk_step(const GridRegs& g, const PathRay& ray,
         const float ty = fmaf((float)(w.c[1] + ay), w.A[1], w.B[1]);
         const float tz = fmaf((float)(w.c[2] + az), w.A[2], w.B[2]);
         const float t_exit = fminf(tx, fminf(ty, tz));
-        const bool stop = b.t < fmaf(t_exit, 1.f - 3.814697265625e-6f, -w.slack);
-        const bool sx = tx <= ty && tx <= tz;
-        const bool sy = !sx && ty <= tz;
+        const bool stop = __uint_as_float((uint32_t)(w.best >> 32)) < fmaf(t_exit, 1.f - 3.814697265625e-6f, -w.slack);
+        const bool sx = (tx <= ty) & (tx <= tz);
+        const bool sy = !sx & (ty <= tz);
         w.c[0] += sx ? 2 * ax - 1 : 0;
         w.c[1] += sy ? 2 * ay - 1 : 0;
-        w.c[2] += (sx || sy) ? 0 : 2 * az - 1;
-        const bool inside = (uint32_t)w.c[0] < (uint32_t)g.n0 && (uint32_t)w.c[1] < (uint32_t)g.n1 &&
-                            (uint32_t)w.c[2] < (uint32_t)g.n2;
-        go = inside && !stop;
-        // cell counts are at most 256 per axis: 24-bit multiplies (full rate) are exact
-        const int32_t ci = go ? __mul24(__mul24(w.c[2], g.n1) + w.c[1], g.n0) + w.c[0] : 0;
-        const uint2 rec = g.cells[ci];
+        w.c[2] += (sx | sy) ? 0 : 2 * az - 1;
+        w.ci += (uint32_t)(sx ? 2 * ax - 1 : (sy ? (2 * ay - 1) * g.n0 : (2 * az - 1) * g.n01));
+        const bool inside = ((uint32_t)w.c[0] < (uint32_t)g.n0) & ((uint32_t)w.c[1] < (uint32_t)g.n1) &
+                            ((uint32_t)w.c[2] < (uint32_t)g.n2);
+        go = inside & !stop;
+        const uint2 rec = g.cells[go ? w.ci : 0u];
         w.e = rec.x;
         w.e_end = go ? rec.x + rec.y : rec.x;
     }
     if (w.e != w.e_end) {
-        exact_test_unordered(b, g.entry_geom[w.e], ray, g.entry_pos[w.e]);
+        walk_test(w, g.entry_geom[w.e], g.entry_pos[w.e], ray);
         ++w.e;
     }
     return go;
@@ -501,7 +505,7 @@ __device__ __forceinline__ void render_f32_body() {
             if constexpr (SCAN == kScanHybrid)
                 scan_hybrid(lds_xy, as_constant(a->filter_zn), as_constant(a->narrow_geom), a->n_narrow_padded, ray, sb);
             else if constexpr (SCAN == kScanGrid)
-                walking = walk_begin(&a->grid, as_constant(a->narrow_geom), ray, sb, walk);
+                walking = walk_begin(&a->grid, as_constant(a->narrow_geom), ray, walk);
             else
                 scan_scalar(as_constant(a->narrow_geom), a->n_narrow_padded, ray, sb);
             fresh = false;
@@ -509,15 +513,21 @@ __device__ __forceinline__ void render_f32_body() {
         if constexpr (SCAN == kScanGrid) {
             // walk until fewer than a quorum of lanes are still on their way (all of them once the queue is empty)
             const int quorum = exhausted ? 1 : kWalkQuorum;
-            const GridRegs gr = {a->grid.n[0], a->grid.n[1], a->grid.n[2], a->grid.cells,
+            const GridRegs gr = {a->grid.n[0], a->grid.n[1], a->grid.n[2], a->grid.n[0] * a->grid.n[1], a->grid.cells,
                                  (const V4*)a->grid.entry_geom, a->grid.entry_pos};
             do {
-                if (walking) walking = walk_step(gr, ray, sb, walk);
+                if (walking) walking = walk_step(gr, ray, walk);
                 ++n_steps;
             } while (__popcll(__ballot(walking)) >= quorum);
         }
 
         if (stage > 0 && !walking) {
+            if constexpr (SCAN == kScanGrid) {
+                const uint32_t low = (uint32_t)walk.best;
+                sb.t = __uint_as_float((uint32_t)(walk.best >> 32));
+                sb.pos = walk.best == kNoHit ? -1 : (int32_t)(low >> 1);
+                sb.far = (low & 1u) != 0u;
+            }
             const float ox = ray.o.x, oy = ray.o.y, oz = ray.o.z, dx = ray.d.x, dy = ray.d.y, dz = ray.d.z;
             const float tmin = ray.tmin;
             float best = sb.t;
