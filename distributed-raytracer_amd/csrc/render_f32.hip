@@ -42,11 +42,12 @@ constexpr uint32_t kNoPixel = 0xFFFFFFFFu;
 #endif
 constexpr int kWalkQuorum = DRAY_WALK_QUORUM;     // grid scan: lanes that must still be walking for the wave to keep stepping
 
-// Waves per SIMD the register allocation of the trace kernel aims at (7 = at most 72 VGPRs; measured fastest: 6 -> 100.6 ms, 7 -> 96.4 ms, 8 -> 102.6 ms per 1200x675x500 frame).
+// Waves per SIMD the register allocation of the brute-force kernels aims at (8 = at most 64 VGPRs; hybrid scan,
+// 1200x675x500 frame: 7 -> 96.4 ms, 8 -> 93.8 ms) and of the grid kernel, which keeps a lane's walk alive across
+// the main loop and wants more registers per lane (4 -> 53.5 ms, 5 -> 47.8 ms, 6 -> 50.6 ms).
 #ifndef DRAY_WAVES_PER_EU
-#define DRAY_WAVES_PER_EU 7
+#define DRAY_WAVES_PER_EU 8
 #endif
-// The grid kernel keeps a lane's walk alive across the main loop and wants more registers per lane.
 #ifndef DRAY_GRID_WAVES_PER_EU
 #define DRAY_GRID_WAVES_PER_EU 5
 #endif
