@@ -75,14 +75,55 @@ __device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x);
 __device__ __forceinline__ float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 
 // vec3.rs:76-84: rejection sampling in the cube; attempt a = words 0..2 of block a of the stage.
-// `w` holds block 0 on entry (the caller computes it once for every kind of scatter).
-__device__ __forceinline__ F3 random_unit_vector(const Stream& st, uint32_t (&w)[4]) {
-    for (uint32_t a = 0;; ++a) {
-        if (a > 0) st.block(a, w);
-        F3 p = {fmaf(2.f, u01<float>(w[0]), -1.f), fmaf(2.f, u01<float>(w[1]), -1.f), fmaf(2.f, u01<float>(w[2]), -1.f)};
-        const float l2 = dot(p, p);
-        if (1e-30f <= l2 && l2 <= 1.f) return p * rsq(l2);
+__device__ __forceinline__ bool unit_vector_attempt(const uint32_t (&w)[4], F3& out) {
+    const F3 p = {fmaf(2.f, u01<float>(w[0]), -1.f), fmaf(2.f, u01<float>(w[1]), -1.f), fmaf(2.f, u01<float>(w[2]), -1.f)};
+    const float l2 = dot(p, p);
+    out = p * rsq(l2);
+    return (1e-30f <= l2) & (l2 <= 1.f);
+}
+
+// The rejection sampler for all lanes of a wave at once.  Called by all 64 lanes (wave-uniform control flow);
+// `want` marks the lanes that need a vector and `w` holds block 0 of their stage.  A lane accepts an attempt with
+// probability pi/6, so run lane by lane the wave would spend the MAXIMUM attempt count over its lanes (about six
+// Philox blocks) with most lanes idle.  Instead, after every lane's own attempt 0, the lanes still pending hand
+// their stream to k = 1, 2, 4 or 8 server lanes each (k * pending <= 64), which evaluate the next k attempts in
+// parallel; the pending lane takes the accepted attempt with the smallest index.  Same streams, same attempts,
+// same winner as the sequential loop -- in about three rounds.  Requests travel through the wave's `req` slots in
+// LDS (LDS keeps one wave's accesses in order), results through lane permutes.
+__device__ __forceinline__ F3 coop_unit_vector(const Stream& st, const uint32_t (&w)[4], bool want, uint4* req, int lane) {
+    F3 res = {0.f, 0.f, 0.f};
+    bool pending = false;
+    if (want) {
+        F3 v;
+        pending = !unit_vector_attempt(w, v);
+        res = v;
     }
+    uint32_t base = 1u; // next attempt index, the same for every pending lane
+    for (unsigned long long pm = __ballot(pending); pm != 0ull; pm = __ballot(pending)) {
+        const uint32_t n_pending = (uint32_t)__popcll(pm);
+        const uint32_t shift = n_pending <= 8u ? 3u : n_pending <= 16u ? 2u : n_pending <= 32u ? 1u : 0u; // log2 k
+        const uint32_t rank = (uint32_t)__popcll(pm & ((1ull << lane) - 1ull));
+        if (pending) req[rank] = make_uint4(st.pixel, st.sample, st.stage, 0u);
+        const uint32_t served = (uint32_t)lane >> shift; // rank of the pending lane this lane serves
+        const bool serving = served < n_pending;
+        const uint4 r = req[serving ? served : 0u];
+        const Stream other = {st.k0, st.k1, r.x, r.y, r.z};
+        uint32_t wb[4];
+        other.block(base + ((uint32_t)lane & ((1u << shift) - 1u)), wb);
+        F3 v;
+        const bool ok = unit_vector_attempt(wb, v) & serving;
+        const unsigned long long okm = __ballot(ok);
+        const uint32_t mine = (uint32_t)(okm >> (rank << shift)) & ((1u << (1u << shift)) - 1u); // my servers' verdicts
+        const bool got = pending & (mine != 0u);
+        const int from = got ? (int)((rank << shift) + (uint32_t)__builtin_ctz(mine)) : lane;
+        const float vx = __shfl(v.x, from, 64), vy = __shfl(v.y, from, 64), vz = __shfl(v.z, from, 64);
+        if (got) {
+            res = {vx, vy, vz};
+            pending = false;
+        }
+        base += 1u << shift;
+    }
+    return res;
 }
 
 struct PathRay {
@@ -391,6 +432,7 @@ __device__ __forceinline__ void render_f32_body() {
     // one wave's accesses in order, and tags and sums are only ever touched by their own wave: no barrier.
     __shared__ unsigned long long lds_sum[4][kSlots][3]; // [wave of the block][slot][r, g, b]
     __shared__ uint32_t lds_tag[4][kSlots];              // the slot's pixel: its Philox pixel word (j * W + i)
+    __shared__ uint4 lds_req[4][64];                     // coop_unit_vector: streams handed to server lanes
     const int wv = (int)(threadIdx.x >> 6);
     if (lane < kSlots) {
         __hip_atomic_store(&lds_tag[wv][lane], kNoPixel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -522,7 +564,13 @@ __device__ __forceinline__ void render_f32_body() {
             } while (__popcll(__ballot(walking)) >= quorum);
         }
 
-        if (stage > 0 && !walking) {
+        // ---- the hit: winner of the narrow scan against the wide spheres, point and normal --------------
+        const bool shading = stage > 0 && !walking;
+        int32_t bidx = -1; // position of the closest sphere in the caller's list
+        F3 hp = {0.f, 0.f, 0.f}, hn = {0.f, 0.f, 0.f};
+        uint32_t mk = 0xFFu; // its material kind; 0xFF: no hit
+        V4 m = {0.f, 0.f, 0.f, 0.f};
+        if (shading) {
             if constexpr (SCAN == kScanGrid) {
                 const uint32_t low = (uint32_t)walk.best;
                 sb.t = __uint_as_float((uint32_t)(walk.best >> 32));
@@ -533,8 +581,6 @@ __device__ __forceinline__ void render_f32_body() {
             const float tmin = ray.tmin;
             float best = sb.t;
             // Re-evaluate the winner from the perpendicular remainder |oc - h d|, which does not cancel.
-            int32_t bidx = -1; // position in the caller's list
-            F3 hp = {0.f, 0.f, 0.f}, hn = {0.f, 0.f, 0.f};
             if (sb.pos >= 0) {
                 bidx = as_constant(a->narrow_index)[sb.pos];
                 const V4 s = as_constant(a->geom32)[bidx];
@@ -560,15 +606,15 @@ __device__ __forceinline__ void render_f32_body() {
                 const double rad = geom64[4 * idx + 3];
                 const double ocx = cx - (double)ox, ocy = cy - (double)oy, ocz = cz - (double)oz;
                 const double ddx = dx, ddy = dy, ddz = dz;
-                const double a = fma(ddz, ddz, fma(ddy, ddy, ddx * ddx));
+                const double aa = fma(ddz, ddz, fma(ddy, ddy, ddx * ddx));
                 const double h = fma(ddz, ocz, fma(ddy, ocy, ddx * ocx));
                 const double c = fma(ocz, ocz, fma(ocy, ocy, fma(ocx, ocx, -(rad * rad))));
-                const double disc = fma(h, h, -(a * c));
+                const double disc = fma(h, h, -(aa * c));
                 if (disc >= 0.) {
                     const float s0f = fsqrt((float)disc);
                     const double s0 = (double)s0f;
                     const double sq = s0f > 0.f ? fma(fma(-s0, s0, disc), (double)(0.5f * rcp(s0f)), s0) : 0.;
-                    const double inva = 2.0 - a;
+                    const double inva = 2.0 - aa;
                     double t = (h - sq) * inva;
                     if (!(t > (double)tmin)) t = (h + sq) * inva;
                     const float tf = (float)t;
@@ -582,29 +628,35 @@ __device__ __forceinline__ void render_f32_body() {
                     }
                 }
             }
+            if (bidx >= 0) {
+                mk = as_constant(a->kind)[bidx];
+                m = as_constant(a->mat32)[bidx];
+            }
+        }
 
-            // ---- shade: camera.rs:270-281 ---------------------------------------------------------
+        // ---- the scatter's uniforms, drawn by the whole wave --------------------------------------
+        // Every scatter that draws at all starts with block 0 of its stage (Lambertian and Metal: first
+        // unit-vector attempt; Dialectric: the reflect/refract uniform).  The further attempts of the rejection
+        // sampler are shared out over all 64 lanes, shading or not (coop_unit_vector).
+        const bool wants_vector = mk == DRAY_MAT_LAMBERTIAN || mk == DRAY_MAT_METAL;
+        const Stream st = {a->key.k0, a->key.k1, gpix, a->key.sample_offset + (ss & 0xFFFFFFu), (uint32_t)stage};
+        uint32_t w[4] = {0u, 0u, 0u, 0u};
+        if (wants_vector || mk == DRAY_MAT_DIELECTRIC) st.block(0, w);
+        // drawn even when a metal's fuzz is 0 (material.rs:75)
+        const F3 ruv = coop_unit_vector(st, w, wants_vector, lds_req[wv], lane);
+
+        // ---- shade: camera.rs:270-281 -------------------------------------------------------------
+        if (shading) {
+            const float dx = ray.d.x, dy = ray.d.y, dz = ray.d.z;
             F3 c = {0.f, 0.f, 0.f};
             bool ended = true;
             if (bidx < 0) { // sky
-                const float a = 0.5f * (dy + 1.0f);
-                const float w = 1.0f - a;
-                c = {thr.x * fmaf(a, 0.5f, w), thr.y * fmaf(a, 0.7f, w), thr.z * fmaf(a, 1.0f, w)};
+                const float ta = 0.5f * (dy + 1.0f);
+                const float tw = 1.0f - ta;
+                c = {thr.x * fmaf(ta, 0.5f, tw), thr.y * fmaf(ta, 0.7f, tw), thr.z * fmaf(ta, 1.0f, tw)};
             } else {
-                const uint32_t mk = as_constant(a->kind)[bidx];
-                const V4 m = as_constant(a->mat32)[bidx];
                 const bool front = dot(ray.d, hn) < 0.f; // hittable.rs:16-22
                 const F3 n = front ? hn : F3{-hn.x, -hn.y, -hn.z};
-                const Stream st = {a->key.k0, a->key.k1, gpix, a->key.sample_offset + (ss & 0xFFFFFFu), (uint32_t)stage};
-                // Every scatter that draws at all starts with block 0 of the stage (Lambertian and Metal: first
-                // unit-vector attempt; Dialectric: the reflect/refract uniform), so it is computed once for all
-                // lanes of the wave, and the unit-vector rejection loop runs once for both materials: under
-                // divergence each separate loop would cost the maximum attempt count over its own lanes.
-                uint32_t w[4];
-                const bool wants_vector = mk == DRAY_MAT_LAMBERTIAN || mk == DRAY_MAT_METAL;
-                if (wants_vector || mk == DRAY_MAT_DIELECTRIC) st.block(0, w);
-                F3 ruv = {0.f, 0.f, 0.f};
-                if (wants_vector) ruv = random_unit_vector(st, w); // drawn even when a metal's fuzz is 0 (material.rs:75)
                 F3 nd = {0.f, 0.f, 0.f};
                 bool scattered = false;
                 if (mk == DRAY_MAT_LAMBERTIAN) { // material.rs:46-56
