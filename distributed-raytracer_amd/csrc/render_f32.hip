@@ -44,12 +44,12 @@ constexpr int kWalkQuorum = DRAY_WALK_QUORUM;     // grid scan: lanes that must 
 
 // Waves per SIMD the register allocation of the brute-force kernels aims at (8 = at most 64 VGPRs; hybrid scan,
 // 1200x675x500 frame: 7 -> 96.4 ms, 8 -> 93.8 ms) and of the grid kernel, which keeps a lane's walk alive across
-// the main loop and wants more registers per lane (4 -> 53.5 ms, 5 -> 47.8 ms, 6 -> 50.6 ms).
+// the main loop and wants more registers per lane (4 -> 50.2 ms, 5 -> 45.0 ms, 6 -> 43.6 ms).
 #ifndef DRAY_WAVES_PER_EU
 #define DRAY_WAVES_PER_EU 8
 #endif
 #ifndef DRAY_GRID_WAVES_PER_EU
-#define DRAY_GRID_WAVES_PER_EU 5
+#define DRAY_GRID_WAVES_PER_EU 6
 #endif
 
 // Pointer into the constant address space: a wave-uniform read through it is a scalar load that the compiler
