@@ -113,10 +113,17 @@ class Stats(C.Structure):
 
 
 # Every symbol include/dray.h declares; tests check that the library exports all of them.
+PIXEL_INDEX_DTYPE = np.dtype([("pixel_i", "<i4"), ("pixel_j", "<i4"), ("pixel_sample_num", "<i4")])
+PATH_ENTRY_DTYPE = np.dtype(
+    [("attenuation", "<f8", 3), ("origin", "<f8", 3), ("direction", "<f8", 3), ("color", "<f8", 3), ("depth", "<i4"),
+     ("stage", "<u4"), ("px", PIXEL_INDEX_DTYPE), ("finished", "<u4"), ("hit_object_or_stop", "<u4"), ("_pad", "<u4")])
+assert PATH_ENTRY_DTYPE.itemsize == 128
+
 EXPORTS = (
     "dray_version", "dray_strerror", "dray_device_count", "dray_opts_default", "dray_camera_default",
     "dray_camera_initialize", "dray_render", "dray_scene_create", "dray_scene_destroy", "dray_render_device",
-    "dray_scene_final", "dray_scene_recipe", "dray_scene_three_spheres", "dray_write_ppm",
+    "dray_scene_final", "dray_scene_recipe", "dray_scene_three_spheres", "dray_write_ppm", "dray_camera_rays",
+    "dray_path_step", "dray_camera_rays_device", "dray_path_step_device",
 )
 
 _lib = None
@@ -166,6 +173,10 @@ def lib():
     L.dray_scene_final.argtypes = [C.c_uint64, C.c_void_p, C.c_size_t]
     L.dray_scene_three_spheres.argtypes = [C.c_void_p, C.c_size_t]
     L.dray_write_ppm.argtypes = [C.c_char_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
+    L.dray_camera_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    L.dray_path_step.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    L.dray_camera_rays_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.dray_path_step_device.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
     L.dray_scene_recipe.argtypes = [C.c_uint64, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_void_p,
                                     C.c_size_t]
     _lib = L

@@ -544,6 +544,98 @@ int render_host_impl(const dray_camera* cam, const dray_sphere* spheres, size_t 
     return rc;
 }
 
+int resolve_device(const dray_opts& opts, int* device) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return DRAY_ERR_NO_DEVICE;
+    *device = opts.device;
+    if (*device < 0) HIP_TRY(hipGetDevice(device));
+    if (*device >= ndev) return DRAY_ERR_INVALID_ARG;
+    return DRAY_OK;
+}
+
+int camera_rays_device_impl(const dray_camera* cam, const dray_pixel_index* d_px, size_t n, dray_path_entry* d_out,
+                            const dray_opts* opts_in, void* stream_v) {
+    if (!camera_ok(cam) || (n && (!d_px || !d_out))) return DRAY_ERR_INVALID_ARG;
+    dray_opts opts;
+    if (opts_in) opts = *opts_in; else dray_opts_default(&opts);
+    dray_camera_derived dv;
+    int rc = dray_camera_initialize(cam, &dv);
+    if (rc) return rc;
+    int device = -1;
+    if ((rc = resolve_device(opts, &device))) return rc;
+    DeviceGuard g(device);
+    if (g.err != hipSuccess) return hip_fail(g.err, "hipSetDevice");
+    const RngKey key = {(uint32_t)opts.seed, (uint32_t)(opts.seed >> 32), opts.sample_offset};
+    HIP_TRY(launch_camera_rays(make_cam<double>(*cam, dv), key, d_px, n, d_out, (hipStream_t)stream_v));
+    return DRAY_OK;
+}
+
+int path_step_device_impl(dray_scene* scene, int32_t image_width, dray_path_entry* d_entries, size_t n,
+                          const dray_opts* opts_in, void* stream_v, bool count) {
+    if (!scene || image_width < 1 || (n && !d_entries)) return DRAY_ERR_INVALID_ARG;
+    dray_opts opts;
+    if (opts_in) opts = *opts_in; else dray_opts_default(&opts);
+    if (opts.device >= 0 && opts.device != scene->device) return DRAY_ERR_INVALID_ARG;
+    DeviceGuard g(scene->device);
+    if (g.err != hipSuccess) return hip_fail(g.err, "hipSetDevice");
+    const RngKey key = {(uint32_t)opts.seed, (uint32_t)(opts.seed >> 32), opts.sample_offset};
+    hipStream_t stream = (hipStream_t)stream_v;
+    if (count) HIP_TRY(hipMemsetAsync(scene->d_counters, 0, sizeof(DeviceCounters), stream));
+    HIP_TRY(launch_path_step(scene->dev, key, image_width, d_entries, n, count ? scene->d_counters : nullptr, stream));
+    return DRAY_OK;
+}
+
+// RAII device buffer for the host-buffer variants
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t n) { return hipMalloc((void**)&p, (n ? n : 1) * sizeof(T)); }
+};
+
+int camera_rays_host_impl(const dray_camera* cam, const dray_pixel_index* px, size_t n, dray_path_entry* out,
+                          const dray_opts* opts_in) {
+    if (!camera_ok(cam) || (n && (!px || !out))) return DRAY_ERR_INVALID_ARG;
+    dray_opts opts;
+    if (opts_in) opts = *opts_in; else dray_opts_default(&opts);
+    int device = -1, rc = resolve_device(opts, &device);
+    if (rc) return rc;
+    DeviceGuard g(device);
+    if (g.err != hipSuccess) return hip_fail(g.err, "hipSetDevice");
+    if (n == 0) return DRAY_OK;
+    DevBuf<dray_pixel_index> d_px;
+    DevBuf<dray_path_entry> d_out;
+    HIP_TRY(d_px.alloc(n));
+    HIP_TRY(d_out.alloc(n));
+    HIP_TRY(hipMemcpy(d_px.p, px, n * sizeof *px, hipMemcpyHostToDevice));
+    opts.device = device;
+    if ((rc = camera_rays_device_impl(cam, d_px.p, n, d_out.p, &opts, nullptr))) return rc;
+    HIP_TRY(hipMemcpy(out, d_out.p, n * sizeof *out, hipMemcpyDeviceToHost));
+    return DRAY_OK;
+}
+
+int path_step_host_impl(dray_scene* scene, int32_t image_width, dray_path_entry* entries, size_t n,
+                        const dray_opts* opts_in, dray_stats* stats) {
+    if (!scene || image_width < 1 || (n && !entries)) return DRAY_ERR_INVALID_ARG;
+    if (stats) std::memset(stats, 0, sizeof *stats);
+    DeviceGuard g(scene->device);
+    if (g.err != hipSuccess) return hip_fail(g.err, "hipSetDevice");
+    if (n == 0) return DRAY_OK;
+    DevBuf<dray_path_entry> d_e;
+    HIP_TRY(d_e.alloc(n));
+    HIP_TRY(hipMemcpy(d_e.p, entries, n * sizeof *entries, hipMemcpyHostToDevice));
+    const int rc = path_step_device_impl(scene, image_width, d_e.p, n, opts_in, nullptr, true);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(entries, d_e.p, n * sizeof *entries, hipMemcpyDeviceToHost));
+    if (stats) {
+        DeviceCounters hc;
+        HIP_TRY(hipMemcpy(&hc, scene->d_counters, sizeof hc, hipMemcpyDeviceToHost));
+        stats->segments = hc.segments;
+        stats->n_spheres = scene->dev.n;
+    }
+    return DRAY_OK;
+}
+
 } // namespace
 
 // ------------------------------------------------------------------ C ABI ----
@@ -657,6 +749,42 @@ int dray_render_device(const dray_camera* cam, dray_scene* scene, uint32_t* d_co
                        size_t buf_len, const dray_opts* opts, void* stream, dray_stats* stats) {
     try {
         return render_device_impl(cam, scene, d_color, d_raw, d_count, buf_len, opts, stream, stats);
+    } catch (...) {
+        return DRAY_ERR_INTERNAL;
+    }
+}
+
+int dray_camera_rays(const dray_camera* cam, const dray_pixel_index* px, size_t n, dray_path_entry* out,
+                     const dray_opts* opts) {
+    try {
+        return camera_rays_host_impl(cam, px, n, out, opts);
+    } catch (...) {
+        return DRAY_ERR_INTERNAL;
+    }
+}
+
+int dray_path_step(dray_scene* scene, int32_t image_width, dray_path_entry* entries, size_t n, const dray_opts* opts,
+                   dray_stats* stats) {
+    try {
+        return path_step_host_impl(scene, image_width, entries, n, opts, stats);
+    } catch (...) {
+        return DRAY_ERR_INTERNAL;
+    }
+}
+
+int dray_camera_rays_device(const dray_camera* cam, const dray_pixel_index* d_px, size_t n, dray_path_entry* d_out,
+                            const dray_opts* opts, void* stream) {
+    try {
+        return camera_rays_device_impl(cam, d_px, n, d_out, opts, stream);
+    } catch (...) {
+        return DRAY_ERR_INTERNAL;
+    }
+}
+
+int dray_path_step_device(dray_scene* scene, int32_t image_width, dray_path_entry* d_entries, size_t n,
+                          const dray_opts* opts, void* stream) {
+    try {
+        return path_step_device_impl(scene, image_width, d_entries, n, opts, stream, false);
     } catch (...) {
         return DRAY_ERR_INTERNAL;
     }

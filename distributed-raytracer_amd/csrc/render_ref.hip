@@ -265,6 +265,81 @@ __global__ __launch_bounds__(256) void render_ref_kernel(CamDev<T> cam, const T*
     }
 }
 
+// CameraRayIterator::next (camera.rs:103-114) + RayColorEntry::new (camera.rs:23-31) for a list of pixel indices.
+__global__ __launch_bounds__(256) void camera_rays_kernel(CamDev<double> cam, RngKey key,
+                                                          const dray_pixel_index* __restrict__ px, size_t n,
+                                                          dray_path_entry* __restrict__ out) {
+    const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const dray_pixel_index id = px[k];
+    const Stream st = {key.k0, key.k1, (uint32_t)id.pixel_j * (uint32_t)cam.W + (uint32_t)id.pixel_i,
+                       key.sample_offset + (uint32_t)id.pixel_sample_num, 0u};
+    V3<double> ro, rd;
+    get_ray(cam, id.pixel_i, id.pixel_j, st, ro, rd);
+    dray_path_entry e = {};
+    e.attenuation[0] = e.attenuation[1] = e.attenuation[2] = 1.;
+    e.origin[0] = ro.x; e.origin[1] = ro.y; e.origin[2] = ro.z;
+    e.direction[0] = rd.x; e.direction[1] = rd.y; e.direction[2] = rd.z;
+    e.depth = cam.max_depth;
+    e.stage = 1u;
+    e.px = id;
+    out[k] = e;
+}
+
+// ray_color_iteration, camera.rs:118-144: one segment of every unfinished path of the batch.
+__global__ __launch_bounds__(256) void path_step_kernel(const double* __restrict__ geom, const double* __restrict__ mat,
+                                                        const uint32_t* __restrict__ kind, int32_t n_spheres, RngKey key,
+                                                        int32_t W, dray_path_entry* __restrict__ entries, size_t n,
+                                                        DeviceCounters* counters) {
+    const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long my_segments = 0;
+    if (k < n && !entries[k].finished) {
+        dray_path_entry e = entries[k];
+        V3<double> att = {e.attenuation[0], e.attenuation[1], e.attenuation[2]};
+        const V3<double> ro = {e.origin[0], e.origin[1], e.origin[2]}, rd = {e.direction[0], e.direction[1], e.direction[2]};
+        const V3<double> zero = {0., 0., 0.};
+        V3<double> c = zero;
+        bool finished = true, hit_or_stop = true;
+        if (e.depth <= 0) { // camera.rs:120-123
+            c = vmul(att, zero);
+        } else {
+            Hit<double> rec;
+            my_segments = 1;
+            if (list_hit<double>(geom, n_spheres, ro, rd, rec)) { // camera.rs:126
+                const Stream st = {key.k0, key.k1, (uint32_t)e.px.pixel_j * (uint32_t)W + (uint32_t)e.px.pixel_i,
+                                   key.sample_offset + (uint32_t)e.px.pixel_sample_num, e.stage};
+                V3<double> sd;
+                const uint32_t mk = kind[rec.index];
+                if (scatter<double>(mk, mat + 4 * rec.index, rd, rec, st, sd)) { // camera.rs:129-133
+                    const V3<double> al = mk == DRAY_MAT_DIELECTRIC
+                                              ? V3<double>{1., 1., 1.}
+                                              : V3<double>{mat[4 * rec.index], mat[4 * rec.index + 1], mat[4 * rec.index + 2]};
+                    att = vmul(att, al);
+                    e.origin[0] = rec.p.x; e.origin[1] = rec.p.y; e.origin[2] = rec.p.z;
+                    e.direction[0] = sd.x; e.direction[1] = sd.y; e.direction[2] = sd.z;
+                    e.depth -= 1;
+                    e.stage += 1u;
+                    finished = false;
+                } else {
+                    c = vmul(att, zero); // camera.rs:135
+                }
+            } else { // camera.rs:140-143
+                const V3<double> ud = vunit(rd);
+                const double t = 0.5 * (ud.y + 1.0);
+                c = vmul(att, vadd(vscale(V3<double>{1.0, 1.0, 1.0}, 1.0 - t), vscale(V3<double>{0.5, 0.7, 1.0}, t)));
+                hit_or_stop = false;
+            }
+        }
+        e.attenuation[0] = att.x; e.attenuation[1] = att.y; e.attenuation[2] = att.z;
+        if (finished) { e.color[0] = c.x; e.color[1] = c.y; e.color[2] = c.z; }
+        e.finished = finished ? 1u : 0u;
+        e.hit_object_or_stop = hit_or_stop ? 1u : 0u;
+        entries[k] = e;
+    }
+    for (int off = 32; off > 0; off >>= 1) my_segments += __shfl_down(my_segments, off, 64);
+    if ((threadIdx.x & 63) == 0 && counters && my_segments) atomicAdd(&counters->segments, my_segments);
+}
+
 template <typename T>
 hipError_t launch_ref(const CamDev<T>& cam, const T* geom, const T* mat, const SceneDev& scene, const Partition& part,
                       const RngKey& key, uint32_t flags, uint32_t* d_color, double* d_raw, int32_t* d_count,
@@ -293,6 +368,25 @@ hipError_t launch_render_ref_f32(const CamDev<float>& cam, const SceneDev& scene
                                  DeviceCounters* d_counters, hipStream_t stream) {
     return launch_ref<float>(cam, scene.geom32, scene.mat32, scene, part, key, flags, d_color, d_raw, d_count,
                              d_counters, stream);
+}
+
+hipError_t launch_camera_rays(const CamDev<double>& cam, const RngKey& key, const dray_pixel_index* d_px, size_t n,
+                              dray_path_entry* d_out, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    const size_t grid = (n + 255) / 256;
+    if (grid > 0x7fffffffu) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(camera_rays_kernel, dim3((unsigned)grid), dim3(256), 0, stream, cam, key, d_px, n, d_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_path_step(const SceneDev& scene, const RngKey& key, int32_t image_width, dray_path_entry* d_entries,
+                            size_t n, DeviceCounters* d_counters, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    const size_t grid = (n + 255) / 256;
+    if (grid > 0x7fffffffu) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(path_step_kernel, dim3((unsigned)grid), dim3(256), 0, stream, scene.geom64, scene.mat64,
+                       scene.kind, scene.n, key, image_width, d_entries, n, d_counters);
+    return hipGetLastError();
 }
 
 } // namespace dray

@@ -98,3 +98,30 @@ def render_device(cam: Camera, scene: DeviceScene, color, raw=None, count=None, 
 def color_to_numpy(color):
     """int32 device colour buffer -> uint32 numpy array with the reference's ARGB packing."""
     return color.detach().cpu().numpy().view(np.uint32)
+
+
+# ------------------------------------------------------- resumable path state --
+
+def camera_rays(cam: Camera, pixel_indices, **opt_overrides):
+    """CameraRayIterator::next (camera.rs:103-114) for each (pixel_i, pixel_j, pixel_sample_num) row, in the given
+    order, followed by RayColorEntry::new(ray, max_depth) (camera.rs:23-31).  Returns a numpy array of
+    PATH_ENTRY_DTYPE records (the reference walks the pixels in a shuffled order, camera.rs:96-98: shuffle the rows)."""
+    px = np.ascontiguousarray(pixel_indices, dtype=np.int32).reshape(-1, 3)
+    out = np.zeros(len(px), dtype=_ffi.PATH_ENTRY_DTYPE)
+    pod = cam.pod()
+    opts = cam.opts(**opt_overrides)
+    _ffi.check(_ffi.lib().dray_camera_rays(C.addressof(pod), px.ctypes.data, len(px), out.ctypes.data,
+                                           C.addressof(opts)))
+    return out
+
+
+def ray_color_iteration(entries, scene: DeviceScene, cam: Camera, **opt_overrides):
+    """One ray_color_iteration (camera.rs:118-144) on every unfinished entry of the batch, in place; returns the
+    call's statistics (segments = entries that were intersected)."""
+    if not (isinstance(entries, np.ndarray) and entries.dtype == _ffi.PATH_ENTRY_DTYPE and entries.flags.c_contiguous):
+        raise _ffi.DrayError(_ffi.ERR_INVALID_ARG, "entries must be a contiguous PATH_ENTRY_DTYPE array")
+    opts = cam.opts(**opt_overrides)
+    st = _ffi.Stats()
+    _ffi.check(_ffi.lib().dray_path_step(scene.handle, int(cam.image_width), entries.ctypes.data, len(entries),
+                                         C.addressof(opts), C.addressof(st)))
+    return st

@@ -176,6 +176,42 @@ void dray_scene_destroy(dray_scene* scene);
 int dray_render_device(const dray_camera* cam, dray_scene* scene, uint32_t* d_color, double* d_raw, int32_t* d_count,
                        size_t buf_len, const dray_opts* opts, void* stream, dray_stats* stats);
 
+/* ---- the path state the reference's distributed layer feeds on ---------------------------- */
+/* PixelIndexEntry, camera.rs:8-13. */
+typedef struct dray_pixel_index {
+    int32_t pixel_i, pixel_j, pixel_sample_num;
+} dray_pixel_index;
+
+/* RayColorEntry (camera.rs:15-21) and RayColorStatus (camera.rs:34-38) of one path, plus what stands in for the
+ * reference's global generator: the path's pixel index and the Philox stage its next scatter draws from. */
+typedef struct dray_path_entry {
+    double attenuation[3];
+    double origin[3], direction[3]; /* ray */
+    double color[3];
+    int32_t depth;
+    uint32_t stage; /* 1 for a fresh camera ray; +1 per scatter */
+    dray_pixel_index px;
+    uint32_t finished, hit_object_or_stop;
+    uint32_t _pad;
+} dray_path_entry;
+
+/* CameraRayIterator::next (camera.rs:103-114) for n pixel indices in the caller's order (the reference walks a
+ * shuffled order, camera.rs:96-98), each followed by RayColorEntry::new(ray, max_depth) (camera.rs:23-31).
+ * f64 arithmetic in the reference's operation order.  Uses opts->seed, sample_offset and device. */
+int dray_camera_rays(const dray_camera* cam, const dray_pixel_index* px, size_t n, dray_path_entry* out,
+                     const dray_opts* opts);
+/* One ray_color_iteration (camera.rs:118-144) on each of n entries, in place: a path is advanced by one segment
+ * and can be resumed by the next call, on this or another GPU, in any batch and order.  Entries whose `finished` is
+ * set are left alone.  image_width is the camera's (it enters the stream key).  f64, the reference's operation
+ * order.  With stats, segments counts the intersected entries. */
+int dray_path_step(dray_scene* scene, int32_t image_width, dray_path_entry* entries, size_t n, const dray_opts* opts,
+                   dray_stats* stats);
+/* The same two calls on device pointers (on the scene's device / opts->device), enqueued on `stream`. */
+int dray_camera_rays_device(const dray_camera* cam, const dray_pixel_index* d_px, size_t n, dray_path_entry* d_out,
+                            const dray_opts* opts, void* stream);
+int dray_path_step_device(dray_scene* scene, int32_t image_width, dray_path_entry* d_entries, size_t n,
+                          const dray_opts* opts, void* stream);
+
 /* ---- scene recipes (host) ------------------------------------------------- */
 /* The scene built by the reference's local binary, main.rs:13-50, with its uniforms taken from the
  * Philox stream (pixel = sample = stage = 0xFFFFFFFF) of `seed`.  Returns the sphere count or a

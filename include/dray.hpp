@@ -206,6 +206,45 @@ class Camera {
     }
 };
 
+// ---- resumable path state (what the reference's distributed layer feeds on) ---------------------------------
+// A HittableList uploaded to one GPU (dray_scene).
+class DeviceScene {
+  public:
+    explicit DeviceScene(const Hittable& world, int32_t device = -1) {
+        std::vector<dray_sphere> spheres;
+        world.flatten(spheres);
+        check(dray_scene_create(spheres.empty() ? nullptr : spheres.data(), spheres.size(), device, &scene_),
+              "dray_scene_create");
+    }
+    ~DeviceScene() { dray_scene_destroy(scene_); }
+    DeviceScene(const DeviceScene&) = delete;
+    DeviceScene& operator=(const DeviceScene&) = delete;
+    dray_scene* handle() const { return scene_; }
+
+  private:
+    dray_scene* scene_ = nullptr;
+};
+
+using PixelIndexEntry = dray_pixel_index; // camera.rs:8-13
+using RayColorEntry = dray_path_entry;    // camera.rs:15-38 (entry and status in one record)
+
+// Camera::iterate_rays (camera.rs:165) for the given pixel indices, in the given order: each yields
+// RayColorEntry::new(get_ray(i, j), max_depth).
+inline std::vector<RayColorEntry> camera_rays(const Camera& cam, const std::vector<PixelIndexEntry>& px) {
+    std::vector<RayColorEntry> out(px.size());
+    const dray_camera c = cam.pod();
+    check(dray_camera_rays(&c, px.data(), px.size(), out.data(), &cam.opts), "camera_rays");
+    return out;
+}
+
+// ray_color_iteration (camera.rs:118-144) on every unfinished entry, in place.  Returns the number intersected.
+inline uint64_t ray_color_iteration(std::vector<RayColorEntry>& entries, const DeviceScene& world, const Camera& cam) {
+    dray_stats st{};
+    check(dray_path_step(world.handle(), cam.image_width, entries.data(), entries.size(), &cam.opts, &st),
+          "ray_color_iteration");
+    return st.segments;
+}
+
 inline void write_ppm(const std::string& path, const std::vector<uint32_t>& color, int32_t width, int32_t height,
                       bool binary = false) {
     if (color.size() < (size_t)width * (size_t)height) throw Error(DRAY_ERR_BUFFER_TOO_SMALL, "write_ppm");

@@ -447,6 +447,79 @@ void orc_ray_color_iterative(const orc_sphere* s, size_t n, const double* ro_in,
     }
 }
 
+/* One call of ray_color_iteration, camera.rs:118-144, on the resumable path state of camera.rs:15-38.
+ * The scatter draws from the Philox stream (pixel, sample, e->stage); a scatter moves the entry on to the next stage. */
+void orc_ray_color_iteration(orc_path_entry* e, const orc_sphere* s, size_t n, uint64_t seed, int32_t image_width,
+                             uint32_t sample_offset) {
+    const double zero[3] = {0., 0., 0.};
+    if (e->depth <= 0) { /* camera.rs:120-123 */
+        orc_v_mul(e->attenuation, zero, e->color);
+        e->finished = 1u; e->hit_object_or_stop = 1u;
+        return;
+    }
+    orc_hit rec;
+    memset(&rec, 0, sizeof rec);
+    if (orc_list_hit(s, n, e->origin, e->direction, 0.001, INFINITY, &rec)) { /* camera.rs:126 */
+        orc_rng rng;
+        memset(&rng, 0, sizeof rng);
+        rng.key[0] = (uint32_t)seed;
+        rng.key[1] = (uint32_t)(seed >> 32);
+        rng.pixel = (uint32_t)e->pixel_j * (uint32_t)image_width + (uint32_t)e->pixel_i;
+        rng.sample = sample_offset + (uint32_t)e->pixel_sample_num;
+        rng.stage = e->stage;
+        double a2[3], so[3], sd[3];
+        if (orc_scatter(&s[rec.index], e->direction, &rec, &rng, a2, so, sd)) { /* camera.rs:129-133 */
+            orc_v_mul(e->attenuation, a2, e->attenuation);
+            memcpy(e->origin, so, sizeof so);
+            memcpy(e->direction, sd, sizeof sd);
+            e->depth -= 1;
+            e->stage += 1u;
+            e->finished = 0u; e->hit_object_or_stop = 1u;
+            return;
+        }
+        orc_v_mul(e->attenuation, zero, e->color); /* camera.rs:135-136 */
+        e->finished = 1u; e->hit_object_or_stop = 1u;
+        return;
+    }
+    double sk[3];
+    sky(e->direction, sk); /* camera.rs:140-142 */
+    orc_v_mul(e->attenuation, sk, e->color);
+    e->finished = 1u; e->hit_object_or_stop = 0u;
+}
+
+/* CameraRayIterator::next for one pixel index (camera.rs:103-114) followed by RayColorEntry::new(ray, max_depth)
+ * (camera.rs:23-31). */
+void orc_camera_ray_entry(const orc_camera* cam, const orc_camera_derived* d, uint64_t seed, uint32_t sample_offset,
+                          int32_t i, int32_t j, int32_t sample, orc_path_entry* e) {
+    orc_rng rng;
+    memset(&rng, 0, sizeof rng);
+    rng.key[0] = (uint32_t)seed;
+    rng.key[1] = (uint32_t)(seed >> 32);
+    rng.pixel = (uint32_t)j * (uint32_t)cam->image_width + (uint32_t)i;
+    rng.sample = sample_offset + (uint32_t)sample;
+    rng.stage = 0u;
+    memset(e, 0, sizeof *e);
+    orc_get_ray(cam, d, i, j, &rng, e->origin, e->direction);
+    e->attenuation[0] = e->attenuation[1] = e->attenuation[2] = 1.;
+    e->depth = cam->max_depth;
+    e->stage = 1u;
+    e->pixel_i = i; e->pixel_j = j; e->pixel_sample_num = sample;
+}
+
+/* The two functions above over a batch (test convenience). px holds (pixel_i, pixel_j, pixel_sample_num) triples. */
+void orc_camera_ray_entries(const orc_camera* cam, uint64_t seed, uint32_t sample_offset, const int32_t* px, size_t n,
+                            orc_path_entry* out) {
+    orc_camera_derived d;
+    orc_camera_initialize(cam, &d);
+    for (size_t k = 0; k < n; ++k)
+        orc_camera_ray_entry(cam, &d, seed, sample_offset, px[3 * k], px[3 * k + 1], px[3 * k + 2], &out[k]);
+}
+void orc_ray_color_iteration_batch(orc_path_entry* e, size_t n_entries, const orc_sphere* s, size_t n, uint64_t seed,
+                                   int32_t image_width, uint32_t sample_offset) {
+    for (size_t k = 0; k < n_entries; ++k)
+        if (!e[k].finished) orc_ray_color_iteration(&e[k], s, n, seed, image_width, sample_offset);
+}
+
 /* --------------------------------------------------------------- Colour -- */
 
 double orc_linear_to_gamma(double x) { /* colors.rs:48-55; NaN > 0 is false, so NaN maps to 0 */

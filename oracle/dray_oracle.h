@@ -148,6 +148,27 @@ void orc_ray_color_recursive(const orc_sphere* s, size_t n, const double* ro, co
 void orc_ray_color_iterative(const orc_sphere* s, size_t n, const double* ro, const double* rd, int32_t depth,
                              orc_rng* rng, double* color, uint64_t* segments);
 
+/* RayColorEntry + RayColorStatus (camera.rs:15-38) with the pixel index (camera.rs:8-13) and the Philox stage that
+ * stand in for the reference's global generator.  Same layout as dray_path_entry. */
+typedef struct orc_path_entry {
+    double attenuation[3];
+    double origin[3], direction[3];
+    double color[3];
+    int32_t depth;
+    uint32_t stage;
+    int32_t pixel_i, pixel_j, pixel_sample_num;
+    uint32_t finished, hit_object_or_stop;
+    uint32_t _pad;
+} orc_path_entry;
+void orc_ray_color_iteration(orc_path_entry* e, const orc_sphere* s, size_t n, uint64_t seed, int32_t image_width,
+                             uint32_t sample_offset);
+void orc_camera_ray_entry(const orc_camera* cam, const orc_camera_derived* d, uint64_t seed, uint32_t sample_offset,
+                          int32_t i, int32_t j, int32_t sample, orc_path_entry* e);
+void orc_camera_ray_entries(const orc_camera* cam, uint64_t seed, uint32_t sample_offset, const int32_t* px, size_t n,
+                            orc_path_entry* out);
+void orc_ray_color_iteration_batch(orc_path_entry* e, size_t n_entries, const orc_sphere* s, size_t n, uint64_t seed,
+                                   int32_t image_width, uint32_t sample_offset);
+
 /* Colour output (src/raytracer/colors.rs). */
 double orc_linear_to_gamma(double x);
 void orc_color_to_rgb(const double* c, uint32_t* rgb);

@@ -98,6 +98,12 @@ class Stats(C.Structure):
     _fields_ = [("segments", C.c_uint64), ("samples", C.c_uint64)]
 
 
+PATH_ENTRY_DTYPE = np.dtype(
+    [("attenuation", "<f8", 3), ("origin", "<f8", 3), ("direction", "<f8", 3), ("color", "<f8", 3), ("depth", "<i4"),
+     ("stage", "<u4"), ("pixel_i", "<i4"), ("pixel_j", "<i4"), ("pixel_sample_num", "<i4"), ("finished", "<u4"),
+     ("hit_object_or_stop", "<u4"), ("_pad", "<u4")])
+assert PATH_ENTRY_DTYPE.itemsize == 128
+
 MAT_DEFAULT, MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC = 0, 1, 2, 3
 
 _lib = None
@@ -161,6 +167,9 @@ def lib():
     L.orc_scene_final.argtypes = [C.c_uint64, P(Sphere), C.c_size_t]
     L.orc_scene_recipe.argtypes = [C.c_uint64, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double, P(Sphere),
                                    C.c_size_t]
+    L.orc_camera_ray_entries.argtypes = [P(Camera), C.c_uint64, C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p]
+    L.orc_ray_color_iteration_batch.argtypes = [C.c_void_p, C.c_size_t, P(Sphere), C.c_size_t, C.c_uint64, C.c_int32,
+                                                C.c_uint32]
     _lib = L
     return L
 
@@ -307,3 +316,19 @@ def render(cam, spheres, seed=1, sample_offset=0, iterative=0, row_begin=0, row_
     if rc != 0:
         raise RuntimeError("orc_render failed: %d" % rc)
     return color, raw, count, st
+
+
+def camera_ray_entries(cam, px, seed=1, sample_offset=0):
+    """CameraRayIterator::next + RayColorEntry::new for (pixel_i, pixel_j, pixel_sample_num) rows of `px`."""
+    px = np.ascontiguousarray(px, dtype=np.int32).reshape(-1, 3)
+    out = np.zeros(len(px), dtype=PATH_ENTRY_DTYPE)
+    lib().orc_camera_ray_entries(C.byref(cam), seed, sample_offset, px.ctypes.data, len(px), out.ctypes.data)
+    return out
+
+
+def ray_color_iteration(entries, spheres, image_width, seed=1, sample_offset=0):
+    """One ray_color_iteration on every unfinished entry, in place."""
+    sp = numpy_to_spheres(spheres)
+    lib().orc_ray_color_iteration_batch(entries.ctypes.data, len(entries), sp, len(spheres), seed, image_width,
+                                        sample_offset)
+    return entries

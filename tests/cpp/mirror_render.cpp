@@ -42,15 +42,49 @@ int main(int argc, char** argv) {
         cam.render(world, [&](const std::vector<uint32_t>&, int32_t w, int32_t h) { presents += (w == W && h == H); },
                    color, raw, count);
         if (presents != 1) return 70;
+        const dray_stats first = cam.last_stats;
         write_ppm(argv[6], color, W, H, false);
         if (argc > 7) {
             std::FILE* f = std::fopen(argv[7], "wb");
             if (!f || std::fwrite(raw.data(), sizeof(double), (size_t)W * H * 3, f) != (size_t)W * H * 3) return 74;
             std::fclose(f);
         }
-        std::printf("{\"width\": %d, \"height\": %d, \"segments\": %llu, \"samples\": %llu, \"spheres\": %d}\n", W, H,
-                    (unsigned long long)cam.last_stats.segments, (unsigned long long)cam.last_stats.samples,
-                    cam.last_stats.n_spheres);
+        // the same frame again through the resumable path state: rays for every (pixel, sample), stepped until all
+        // are finished, colours summed per pixel in sample order (left-to-right product, camera.rs:118-144)
+        unsigned long long step_segments = 0;
+        double worst = 0.0;
+        if (cam.opts.mode == DRAY_MODE_F64) {
+            cam.opts.flags |= DRAY_FLAG_ITERATIVE_PRODUCT;
+            std::vector<uint32_t> color2((size_t)W * W, 0u);
+            std::vector<double> raw2((size_t)W * W * 3, 0.0);
+            std::vector<int32_t> count2((size_t)W * W, 0);
+            cam.render(world, color2, raw2, count2);
+            std::vector<PixelIndexEntry> px;
+            for (int32_t s = 0; s < cam.samples_per_pixel; ++s)
+                for (int32_t j = 0; j < H; ++j)
+                    for (int32_t i = 0; i < W; ++i) px.push_back(PixelIndexEntry{i, j, s});
+            DeviceScene scene(world);
+            std::vector<RayColorEntry> entries = camera_rays(cam, px);
+            for (int guard = 0; guard <= cam.max_depth + 1; ++guard) {
+                const uint64_t moved = ray_color_iteration(entries, scene, cam);
+                step_segments += moved;
+                if (moved == 0) break;
+            }
+            std::vector<double> sum((size_t)W * H * 3, 0.0);
+            for (const RayColorEntry& e : entries) {
+                if (!e.finished) return 71;
+                for (int q = 0; q < 3; ++q) sum[3 * ((size_t)e.px.pixel_j * W + e.px.pixel_i) + q] += 0.0 + e.color[q];
+            }
+            for (size_t k = 0; k < sum.size(); ++k) {
+                const double d = sum[k] > raw2[k] ? sum[k] - raw2[k] : raw2[k] - sum[k];
+                if (d > worst) worst = d;
+            }
+            if (worst != 0.0 || step_segments != cam.last_stats.segments) return 72;
+            cam.opts.flags &= ~(uint32_t)DRAY_FLAG_ITERATIVE_PRODUCT;
+        }
+        std::printf("{\"width\": %d, \"height\": %d, \"segments\": %llu, \"samples\": %llu, \"spheres\": %d, "
+                    "\"step_segments\": %llu}\n", W, H, (unsigned long long)first.segments,
+                    (unsigned long long)first.samples, first.n_spheres, step_segments);
     } catch (const Error& e) {
         std::fprintf(stderr, "%s\n", e.what());
         return -e.status;

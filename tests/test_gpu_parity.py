@@ -515,3 +515,44 @@ def test_cpp_mirror_matches_python_binding(dray, gpu, oracle, tmp_path):
     assert info["segments"] == cam.last_stats.segments
     ocol, oraw, _, ost = oracle.render(ocam_from(oracle, cam), dray.flatten_world(world), seed=21)
     assert (oraw == raw[:W * H].reshape(H, W, 3)).all() and ost.segments == info["segments"]
+
+
+def test_path_step_matches_oracle(dray, gpu, oracle):
+    """dray_camera_rays / dray_path_step (CameraRayIterator::next, ray_color_iteration; camera.rs:103-144): every
+    field of every entry equals the oracle's after every step, for a shuffled pixel order (camera.rs:96-98), and the
+    finished colours add up to the f64 iterative-product render."""
+    spheres = dray.scene_final(1)
+    cam = dray.camera_final(width=40, spp=2, depth=10)
+    cam.mode, cam.seed = dray.MODE_F64, 9
+    H, W = cam.initialize().image_height, cam.image_width
+    oc = ocam_from(oracle, cam)
+    px = np.array([(i, j, s) for s in range(2) for j in range(H) for i in range(W)], dtype=np.int32)
+    order = np.random.default_rng(3).permutation(len(px))
+    e = gpu.camera_rays(cam, px[order])
+    oe = oracle.camera_ray_entries(oc, px[order], seed=9)
+    assert e.tobytes() == oe.tobytes()
+    scene = gpu.DeviceScene(spheres, 0)
+    segments = 0
+    for step in range(12):
+        if (e["finished"] == 1).all():
+            break
+        st = gpu.ray_color_iteration(e, scene, cam)
+        oracle.ray_color_iteration(oe, spheres, W, seed=9)
+        segments += st.segments
+        assert e.tobytes() == oe.tobytes(), step
+    assert (e["finished"] == 1).all()
+    # resumed on a smaller batch, in another order: same result (the state is all a path needs)
+    e2 = gpu.camera_rays(cam, px[order][::7])
+    for _ in range(12):
+        gpu.ray_color_iteration(e2[::-1].copy(), scene, cam)  # a copy: the call must not depend on hidden state
+        gpu.ray_color_iteration(e2, scene, cam)
+    assert e2.tobytes() == e[::7].tobytes()
+    scene.close()
+    cam.flags = dray.FLAG_ITERATIVE_PRODUCT
+    col, raw, cnt, rst = render_gpu(dray, gpu, spheres, cam, seed=9)
+    assert segments == rst.segments
+    total = np.zeros((H, W, 3))
+    inv = np.argsort(order, kind="stable")
+    for k in inv:  # back to sample-major order: each pixel adds its samples in order
+        total[e["px"]["pixel_j"][k], e["px"]["pixel_i"][k]] += 0.0 + e["color"][k]
+    assert (total == raw).all()

@@ -323,3 +323,43 @@ def test_scene_final_recipe():
     assert (metal["albedo"] >= 0.5).all() and (metal["albedo"] < 1.0).all() and (metal["fuzz_or_ior"] < 0.5).all()
     assert (small[small["kind"] == O.MAT_DIELECTRIC]["fuzz_or_ior"] == 1.5).all()
     assert len(O.scene_final(2)) != 0 and not (O.scene_final(2)["center"][1] == sp["center"][1]).all()
+
+
+def test_ray_color_iteration_steps_equal_the_whole_path(oracle):
+    """Driving ray_color_iteration (camera.rs:118-144) to completion from the iterator's rays (camera.rs:103-114)
+    reproduces the left-to-right product render: the sum of the finished entries' colours, in sample order, equals
+    the raw buffer of the iterative render bit for bit, and the number of intersected entries equals its segments."""
+    spheres = oracle.scene_final(1)
+    cam = oracle.camera_final(width=24, spp=3, depth=12)
+    H, W = oracle.image_height(cam), cam.image_width
+    _, raw, _, st = oracle.render(cam, spheres, seed=5, iterative=1)
+    px = np.array([(i, j, s) for s in range(3) for j in range(H) for i in range(W)], dtype=np.int32)
+    e = oracle.camera_ray_entries(cam, px, seed=5)
+    assert (e["depth"] == 12).all() and (e["stage"] == 1).all() and (e["attenuation"] == 1.0).all()
+    assert (e["finished"] == 0).all()
+    segments = 0
+    for _ in range(13):
+        live = int((e["finished"] == 0).sum())
+        if not live:
+            break
+        before = e.copy()
+        oracle.ray_color_iteration(e, spheres, W, seed=5)
+        segments += int(((before["finished"] == 0) & (before["depth"] > 0)).sum())
+        moved = (before["finished"] == 0) & (e["finished"] == 0)
+        assert (e["depth"][moved] == before["depth"][moved] - 1).all()
+        assert (e["stage"][moved] == before["stage"][moved] + 1).all()
+        assert (e["hit_object_or_stop"][moved] == 1).all()
+    assert (e["finished"] == 1).all()
+    assert segments == st.segments
+    total = np.zeros((H, W, 3))
+    for k in range(len(e)):  # sample-major order of px: each pixel adds its samples in order, as colors.rs:38 does
+        total[e["pixel_j"][k], e["pixel_i"][k]] += 0.0 + e["color"][k]
+    assert (total == raw).all()
+    # RayColorStatus: sky misses report hit_object_or_stop = false (camera.rs:143), everything else true
+    sky = e["hit_object_or_stop"] == 0
+    assert sky.any() and (e["color"][sky].sum(axis=1) > 0).all()
+    # depth exhausted: one more call finishes the entry with colour attenuation * 0 (camera.rs:120-123)
+    z = oracle.camera_ray_entries(cam, px[:1], seed=5)
+    z["depth"] = 0
+    oracle.ray_color_iteration(z, spheres, W, seed=5)
+    assert z["finished"][0] == 1 and z["hit_object_or_stop"][0] == 1 and (z["color"][0] == 0).all()
