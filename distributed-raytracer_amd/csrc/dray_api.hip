@@ -166,13 +166,26 @@ void build_grid(const std::vector<float>& ng, int32_t n_narrow, GridHost& g) {
     g = GridHost();
     if (n_narrow <= 0) return;
     std::vector<double> rad(n_narrow);
+    std::vector<char> odd(n_narrow, 0); // not finite: never hit by the exact test either; kept out of the grid
     double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    int32_t n_regular = 0;
     for (int32_t p = 0; p < n_narrow; ++p) {
         rad[p] = std::sqrt((double)ng[4 * p + 3]) * (1.0 + 1e-6);
+        if (!std::isfinite(rad[p]) || !std::isfinite(ng[4 * p]) || !std::isfinite(ng[4 * p + 1]) ||
+            !std::isfinite(ng[4 * p + 2])) {
+            odd[p] = 1;
+            continue;
+        }
+        ++n_regular;
         for (int a = 0; a < 3; ++a) {
             lo[a] = std::fmin(lo[a], (double)ng[4 * p + a] - rad[p]);
             hi[a] = std::fmax(hi[a], (double)ng[4 * p + a] + rad[p]);
         }
+    }
+    if (n_regular == 0) { // nothing to walk: every sphere goes to the loose list
+        for (int32_t p = 0; p < n_narrow; ++p) g.loose.push_back(p);
+        g.dev.n_loose = (int32_t)g.loose.size();
+        return;
     }
     double ext[3], biggest = 0., reach = 0.;
     for (int a = 0; a < 3; ++a) {
@@ -208,7 +221,7 @@ void build_grid(const std::vector<float>& ng, int32_t n_narrow, GridHost& g) {
         margin = margin / 256. + 1e-5 * reach; // a sphere is listed wherever its ball grown by this overlaps
         const size_t n_cells = (size_t)n[0] * n[1] * n[2];
         std::vector<uint32_t> count(n_cells, 0u);
-        std::vector<char> is_loose(n_narrow, 0);
+        std::vector<char> is_loose(odd);
         size_t total = 0;
         auto for_cells = [&](int32_t p, auto&& visit) { // cells the grown ball of sphere p overlaps
             const double r = rad[p] + margin;
@@ -231,6 +244,7 @@ void build_grid(const std::vector<float>& ng, int32_t n_narrow, GridHost& g) {
                     }
         };
         for (int32_t p = 0; p < n_narrow; ++p) {
+            if (is_loose[p]) continue;
             size_t span = 0;
             for_cells(p, [&](size_t) { ++span; });
             if (span > kGridSpanLimit) {

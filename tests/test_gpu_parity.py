@@ -233,6 +233,24 @@ def test_f32_grid_scan_equals_scalar_scan_on_random_scenes(dray, gpu):
             b = render_gpu(dray, gpu, spheres, cam, seed=19, variant=dray.SCAN_GRID)
             same = (a[0] == b[0]).all() and (a[1] == b[1]).all() and a[3].segments == b[3].segments
             assert same, (name, lookfrom, int((a[0] != b[0]).sum()), a[3].segments, b[3].segments)
+    # degenerate inputs: zero radius, non-finite centre or radius (never hit, kept out of the grid), all spheres in
+    # one spot, and an empty narrow list (only a wide sphere)
+    odd = soup(rng, 120, 3.0, 0.1, 0.6)
+    odd["radius"][:5] = 0.0
+    odd["center"][5] = (np.nan, 0.0, 0.0)
+    odd["center"][6] = (np.inf, 0.0, 0.0)
+    odd["radius"][7] = np.nan
+    odd["center"][8:40] = (0.5, 0.5, 0.5)
+    only_wide = soup(rng, 0, 1.0, 0.1, 0.2, extra=[((0.0, -1001.0, 0.0), 1000.0)])
+    all_nan = soup(rng, 70, 1.0, 0.1, 0.2)
+    all_nan["center"][:, 0] = np.nan
+    for name, spheres in (("odd", odd), ("only_wide", only_wide), ("all_nan", all_nan)):
+        cam = dray.camera_final(width=64, spp=4, depth=20)
+        cam.mode = dray.MODE_F32
+        cam.lookfrom, cam.lookat, cam.vfov, cam.defocus_angle = (6.0, 3.0, 5.0), (0.0, 0.0, 0.0), 50.0, 0.0
+        a = render_gpu(dray, gpu, spheres, cam, seed=23, variant=dray.SCAN_SCALAR)
+        b = render_gpu(dray, gpu, spheres, cam, seed=23, variant=dray.SCAN_GRID)
+        assert (a[0] == b[0]).all() and (a[1] == b[1]).all() and a[3].segments == b[3].segments, name
     # an axis-parallel bundle: zero direction components take the walk's parallel-ray branch
     cam = dray.camera_final(width=33, spp=2, depth=8)
     cam.mode = dray.MODE_F32
