@@ -44,11 +44,16 @@ def deinterleave(gathered, image_height, world_size):
     return full[:image_height]
 
 
-def gather_image(slab, image_height, group=None):
-    """All-gather the per-rank colour slabs [slab_rows, W] and return the full [H, W] image on every rank."""
+def gather_image(slab, image_height, group=None, always_collective=False):
+    """All-gather the per-rank colour slabs [slab_rows, W] and return the full [H, W] image on every rank.
+
+    A single rank returns its slab without a collective unless ``always_collective`` is set (tests use it to run
+    the RCCL call on one GPU)."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()):
+        return slab[:image_height]
+    if dist.get_world_size(group) == 1 and not always_collective:
         return slab[:image_height]
     G = dist.get_world_size(group)
     S, W = slab.shape

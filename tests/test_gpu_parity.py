@@ -574,3 +574,31 @@ def test_path_step_matches_oracle(dray, gpu, oracle):
     for k in inv:  # back to sample-major order: each pixel adds its samples in order
         total[e["px"]["pixel_j"][k], e["px"]["pixel_i"][k]] += 0.0 + e["color"][k]
     assert (total == raw).all()
+
+
+def test_rccl_gather_on_one_gpu(dray, gpu):
+    """The collective of the multi-GPU path (one all_gather_into_tensor of the packed int32 slabs over the "nccl"
+    backend = RCCL) run on a one-rank group: the gathered image equals the plain render."""
+    import torch
+    import torch.distributed as dist
+    from dray_amd import partition
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29533", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        spheres = dray.scene_final(1)
+        cam = dray.camera_final(width=96, spp=4, depth=20)
+        cam.mode = dray.MODE_F32
+        full = render_gpu(dray, gpu, spheres, cam, seed=cam.seed)
+        scene = gpu.DeviceScene(spheres, 0)
+        r = partition.DistributedRenderer(cam, partition.gpu_render_rows(scene), partition.gpu_alloc(0), rank=0,
+                                          world_size=1)
+        _, st = r.step(gather=False)
+        image = partition.gather_image(r.color, r.H, None, always_collective=True)
+        torch.cuda.synchronize()
+        assert (gpu.color_to_numpy(image.contiguous()) == full[0]).all() and st.segments == full[3].segments
+        scene.close()
+    finally:
+        dist.destroy_process_group()
