@@ -602,3 +602,27 @@ def test_rccl_gather_on_one_gpu(dray, gpu):
         scene.close()
     finally:
         dist.destroy_process_group()
+
+
+def test_converged_image_against_independent_oracle_render(dray, gpu, oracle):
+    """Statistical check beyond same-stream parity: the f32 grid render with one seed against oracle renders with
+    other seeds at 256 spp.  The GPU image must sit at the Monte-Carlo noise floor, i.e. its RMSE to an oracle
+    render is no larger than the RMSE between two oracle renders (x1.15), and PSNR on the 8-bit image >= 30 dB."""
+    spheres = dray.scene_final(1)
+    cam = dray.camera_final(width=64, spp=256, depth=50)
+    cam.mode = dray.MODE_F32
+    col, raw, cnt, st = render_gpu(dray, gpu, spheres, cam, seed=101)
+    oc = ocam_from(oracle, cam)
+    _, r1, _, _ = oracle.render(oc, spheres, seed=202, threads=16)
+    _, r2, _, _ = oracle.render(oc, spheres, seed=303, threads=16)
+    mean = lambda r: np.clip(r / 256.0, 0.0, 1.0)
+    rmse = lambda a, b: float(np.sqrt(np.mean((mean(a) - mean(b)) ** 2)))
+    floor = rmse(r1, r2)
+    got = 0.5 * (rmse(raw, r1) + rmse(raw, r2))
+    g8 = channels(col).astype(np.float64)
+    o8 = 255.999 * np.sqrt(mean(r1)).clip(0, 0.999)
+    psnr = 10.0 * np.log10(255.0 ** 2 / np.mean((g8 - np.floor(o8)) ** 2))
+    report("converged_f32_vs_independent_oracle_64x36_256spp", rmse_gpu_vs_oracle=got, rmse_oracle_vs_oracle=floor,
+           psnr_8bit_db=float(psnr))
+    assert got <= 1.15 * floor
+    assert psnr >= 30.0
