@@ -111,7 +111,8 @@ hipError_t launch_path_step(const SceneDev& scene, const RngKey& key, int32_t im
 
 // render_f32.hip
 struct F32Plan {
-    int32_t pixels_per_pool;  // consecutive pixels a wave takes from the global queue at a time
+    int32_t pixels_per_pool;  // consecutive pixels a wave hands out to its lanes at a time
+    int32_t grab_pixels;      // pixels a wave takes from the global queue per atomic
     size_t accum_words;       // 3 * n_rows * W fixed-point sums (u64), zeroed before the launch
     int32_t grid, block;
     size_t lds_bytes;         // dynamic LDS of the launch

@@ -23,6 +23,8 @@
 // cycles; f32 matrix instructions run on the same ALUs.  So the scan minimises VGPR-only ALU operations per
 // ray-sphere test and keeps the SGPR-sourced ones under ~60 % of the mix (scan_hybrid below: 8 operations, 3
 // of them SGPR-sourced, against 11 and 4 for the direct form of sphere.rs:29-36).
+#include <cstdlib>
+
 #include "dray_device.h"
 #include "dray_internal.h"
 
@@ -33,7 +35,8 @@ constexpr float kFixScale = 268435456.f;      // 2^28
 constexpr double kFixInv = 1.0 / 268435456.0; // 2^-28
 constexpr float kFixMax = 15.99f;             // a sample colour channel is clamped to [0, 15.99]
 constexpr int kUnroll = 8;                    // spheres per scan block (the tables are padded to a multiple)
-constexpr int kPoolSamples = 64;               // samples a wave aims to take from the global queue per atomic
+constexpr int kPoolSamples = 64;               // samples a pool holds at least (one per lane)
+constexpr int kGrabWork = 16384;               // sphere tests' worth of samples a wave aims to take from the queue per atomic
 constexpr float kSlack = 7.62939453125e-6f;   // 2^-17, see scan_hybrid
 constexpr int kSlots = 32;                     // pixel sums a wave keeps in LDS before they go to memory
 constexpr uint32_t kNoPixel = 0xFFFFFFFFu;
@@ -396,6 +399,7 @@ struct F32Args {
     Partition part;
     RngKey key;
     int32_t pixels_per_pool;
+    int32_t grab_pixels; // pixels a wave takes from the global queue per atomic (a multiple of pixels_per_pool)
     unsigned long long* accum;
     DeviceCounters* counters;
 };
@@ -485,6 +489,8 @@ __device__ __forceinline__ void render_f32_body() {
     uint32_t pool_slot = 0u, pool_pixels = 0u;         // cache slot of the pool's first pixel, pixels in the pool
     unsigned long long n_samples = 0ull;               // samples of the pools this wave has opened
     uint32_t n_steps = 0u;                             // grid scan: steps this wave has taken
+    uint32_t grab_next = 0u, grab_end = 0u;            // pixels grabbed from the global queue, not yet in a pool
+    uint32_t grab_pixels = (uint32_t)a->grab_pixels;   // size of the next grab
     bool exhausted = false;
 
     for (;;) {
@@ -494,17 +500,32 @@ __device__ __forceinline__ void render_f32_body() {
         unsigned long long want = __ballot(need);
         while (want != 0ull) {
             const uint32_t W = (uint32_t)a->cam.W, spp = (uint32_t)a->cam.spp;
-            if (pool_q == pool_n && !exhausted) { // one returning atomic on the global pixel counter opens a pool
+            if (pool_q == pool_n && !exhausted) { // open the next pool
                 const uint32_t npix = pixel_count(), pixels_per_pool = (uint32_t)a->pixels_per_pool;
-                unsigned long long base = 0ull;
-                if (lane == 0) base = atomicAdd(&a->counters->next_item, (unsigned long long)pixels_per_pool);
-                const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)base, 0);
-                const uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(base >> 32), 0);
-                if (hi != 0u || lo >= npix) {
-                    exhausted = true;
-                } else {
+                if (grab_next == grab_end) {
+                    // One returning atomic on the global pixel counter grabs pixels for several pools: the counter
+                    // sustains only ~80 M returning atomics per second (a 100-spp frame with one atomic per pixel
+                    // was bound by exactly that), so a grab covers several pools (plan_render_f32 sizes it).  Grabs shrink as the
+                    // queue drains (half the remaining pixels spread over all waves), which keeps the last waves'
+                    // tail short.
+                    unsigned long long base = 0ull;
+                    if (lane == 0) base = atomicAdd(&a->counters->next_item, (unsigned long long)grab_pixels);
+                    const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)base, 0);
+                    const uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(base >> 32), 0);
+                    if (hi != 0u || lo >= npix) {
+                        exhausted = true;
+                    } else {
+                        grab_next = lo;
+                        grab_end = lo + min(grab_pixels, npix - lo);
+                        const uint32_t fair = (npix - grab_end) / (2u * gridDim.x * (blockDim.x >> 6));
+                        grab_pixels = max(pixels_per_pool, min((uint32_t)a->grab_pixels, fair));
+                    }
+                }
+                if (!exhausted) {
+                    const uint32_t lo = grab_next;
                     pool_slot = (pool_slot + pool_pixels) & (uint32_t)(kSlots - 1);
-                    pool_pixels = min(pixels_per_pool, npix - lo);
+                    pool_pixels = min(pixels_per_pool, grab_end - lo);
+                    grab_next = lo + pool_pixels;
                     pool_pix = lo;
                     pool_q = 0u;
                     pool_n = pool_pixels * spp;
@@ -800,6 +821,19 @@ F32Plan plan_render_f32(const CamDev<float>& cam, const Partition& part, int32_t
     int32_t ppp = pixels_per_pool > 0 ? pixels_per_pool : (kPoolSamples + spp - 1) / spp; // >= kPoolSamples samples ...
     if (ppp > kSlots / 2) ppp = kSlots / 2; // ... while the previous pool's pixels stay cached
     plan.pixels_per_pool = ppp;
+    // Cheap samples drain the queue fast and need big grabs to stay under the counter's atomic rate; dear ones
+    // (a long brute-force scan per segment) need small grabs to keep the last waves' tail short.  Measured: 3-sphere
+    // full-HD frame 13.2 / 9.6 / 9.3 ms at 256 / 512 / 1024 samples per grab, 485-sphere hybrid scan 21.0 / 22.1 /
+    // 25.4 ms, grid scan 9.7 / 9.5 / 9.8 ms (100 spp).
+    const int32_t tests_per_segment = plan.scan == DRAY_SCAN_GRID ? 32 : scene.n_narrow_padded;
+    int32_t grab_samples = kGrabWork / (tests_per_segment + 16);
+    grab_samples = grab_samples < 128 ? 128 : (grab_samples > 1024 ? 1024 : grab_samples);
+    if (const char* env = std::getenv("DRAY_GRAB_SAMPLES")) { // tuning runs only
+        const int v = std::atoi(env);
+        if (v > 0) grab_samples = v;
+    }
+    int32_t pools = grab_samples / (ppp * spp);
+    plan.grab_pixels = ppp * (pools < 1 ? 1 : (pools > 64 ? 64 : pools));
     plan.accum_words = (size_t)3 * (size_t)(npix > 0 ? npix : 0);
     const long long blocks_needed = (npix * spp + plan.block - 1) / plan.block;
     if (blocks_needed < plan.grid) plan.grid = (int32_t)(blocks_needed > 0 ? blocks_needed : 1);
@@ -821,7 +855,7 @@ hipError_t launch_render_f32(const CamDev<float>& cam, const SceneDev& scene, co
     args.geom64 = t.geom64; args.geom32 = (const V4*)t.geom32; args.mat32 = (const V4*)t.mat32; args.kind = t.kind;
     args.n_narrow_padded = t.n_narrow_padded; args.n_wide = t.n_wide;
     args.grid = scene.grid;
-    args.part = part; args.key = key; args.pixels_per_pool = plan.pixels_per_pool;
+    args.part = part; args.key = key; args.pixels_per_pool = plan.pixels_per_pool; args.grab_pixels = plan.grab_pixels;
     args.accum = d_accum; args.counters = d_counters;
     auto launch = [&](auto kernel) {
         hipLaunchKernelGGL(kernel, dim3(plan.grid), dim3(plan.block), plan.lds_bytes, stream, args);
