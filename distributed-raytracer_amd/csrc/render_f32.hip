@@ -579,9 +579,10 @@ __device__ __forceinline__ void render_f32_body() {
             const int quorum = exhausted ? 1 : kWalkQuorum;
             const GridRegs gr = {a->grid.n[0], a->grid.n[1], a->grid.n[2], a->grid.n[0] * a->grid.n[1], a->grid.cells,
                                  (const V4*)a->grid.entry_geom, a->grid.entry_pos};
-            do {
+            do { // two steps per count: the count is scalar-unit work every walking lane waits for
                 if (walking) walking = walk_step(gr, ray, walk);
-                ++n_steps;
+                if (walking) walking = walk_step(gr, ray, walk);
+                n_steps += 2u;
             } while (__popcll(__ballot(walking)) >= quorum);
         }
 
