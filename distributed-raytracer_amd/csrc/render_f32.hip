@@ -486,6 +486,8 @@ __device__ __forceinline__ void render_f32_body() {
     Walk walk = {};
     // wave-uniform queue state
     uint32_t pool_pix = 0u, pool_q = 0u, pool_n = 0u; // first pixel, next sample, sample count of the pool
+    uint32_t pool_r0 = 0u, pool_i0 = 0u;               // row and column of the pool's first pixel in the partition
+    uint32_t pool_dp = 0u, pool_smp = 0u;              // pool_q as (pixel, sample), kept when `stepwise`
     uint32_t pool_slot = 0u, pool_pixels = 0u;         // cache slot of the pool's first pixel, pixels in the pool
     unsigned long long n_samples = 0ull;               // samples of the pools this wave has opened
     uint32_t n_steps = 0u;                             // grid scan: steps this wave has taken
@@ -500,6 +502,9 @@ __device__ __forceinline__ void render_f32_body() {
         unsigned long long want = __ballot(need);
         while (want != 0ull) {
             const uint32_t W = (uint32_t)a->cam.W, spp = (uint32_t)a->cam.spp;
+            // at least one sample per lane in a pixel and rows longer than a pool: a hand-out wraps at most once
+            // (not in the grid kernel: it has no register to spare, and the walk dwarfs the two divisions)
+            const bool stepwise = SCAN != kScanGrid && spp >= 64u && W >= (uint32_t)kSlots;
             if (pool_q == pool_n && !exhausted) { // open the next pool
                 const uint32_t npix = pixel_count(), pixels_per_pool = (uint32_t)a->pixels_per_pool;
                 if (grab_next == grab_end) {
@@ -527,7 +532,9 @@ __device__ __forceinline__ void render_f32_body() {
                     pool_pixels = min(pixels_per_pool, grab_end - lo);
                     grab_next = lo + pool_pixels;
                     pool_pix = lo;
-                    pool_q = 0u;
+                    pool_r0 = lo / W;
+                    pool_i0 = lo - pool_r0 * W;
+                    pool_q = pool_dp = pool_smp = 0u;
                     pool_n = pool_pixels * spp;
                     n_samples += (unsigned long long)pool_n;
                     retire_slots(pool_slot, lo, pool_pixels, true);
@@ -542,12 +549,24 @@ __device__ __forceinline__ void render_f32_body() {
             const uint32_t take = wanted < avail ? wanted : avail;
             const uint32_t rank = (uint32_t)__popcll(want & ((1ull << lane) - 1ull));
             if (need && rank < take) {
-                // (two integer divisions per hand-out; replacing them by conditional steps measured no faster)
-                const uint32_t q = pool_q + rank;
-                const uint32_t dp = q / spp, smp = q - dp * spp;
-                const uint32_t pix = pool_pix + dp;
-                const uint32_t r = pix / W;
-                const int32_t pi = (int32_t)(pix - r * W), pj = a->part.row_begin + (int32_t)r * a->part.row_step;
+                // the lane's place in the pool: pixel `dp` places after the pool's first, sample `smp` of it
+                uint32_t dp, smp, r, i;
+                if (stepwise) { // one conditional step each instead of two integer divisions per hand-out
+                    smp = pool_smp + rank;
+                    dp = pool_dp;
+                    if (smp >= spp) { smp -= spp; dp++; }
+                    i = pool_i0 + dp;
+                    r = pool_r0;
+                    if (i >= W) { i -= W; r++; }
+                } else {
+                    const uint32_t q = pool_q + rank;
+                    dp = q / spp;
+                    smp = q - dp * spp;
+                    const uint32_t pix = pool_pix + dp;
+                    r = pix / W;
+                    i = pix - r * W;
+                }
+                const int32_t pi = (int32_t)i, pj = a->part.row_begin + (int32_t)r * a->part.row_step;
                 gpix = (uint32_t)pj * W + (uint32_t)pi;
                 ss = smp | (((pool_slot + dp) & (uint32_t)(kSlots - 1)) << 24);
                 const Stream st = {a->key.k0, a->key.k1, gpix, a->key.sample_offset + smp, 0u};
@@ -558,6 +577,8 @@ __device__ __forceinline__ void render_f32_body() {
                 need = false;
             }
             pool_q += take;
+            pool_smp += take;
+            if (pool_smp >= spp) { pool_smp -= spp; pool_dp++; } // only read when stepwise
             want = __ballot(need);
         }
         if (__ballot(stage > 0) == 0ull) break;
