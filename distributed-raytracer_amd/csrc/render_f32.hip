@@ -142,10 +142,10 @@ __device__ __forceinline__ void set_dir(PathRay& r, F3 dir) {
 }
 
 // camera.rs:238-262
-__device__ __forceinline__ void camera_ray(ConstPtr<CamDev<float>> camp, int32_t i, int32_t j, const Stream& st, PathRay& r) {
+// `w` holds block 0 of the sample's stage-0 stream on entry.
+__device__ __forceinline__ void camera_ray(ConstPtr<CamDev<float>> camp, int32_t i, int32_t j, const Stream& st,
+                                           uint32_t (&w)[4], PathRay& r) {
     const DRAY_CONSTANT CamDev<float>& cam = *camp;
-    uint32_t w[4];
-    st.block(0, w);
     const float fx = (float)i + (u01<float>(w[0]) - 0.5f), fy = (float)j + (u01<float>(w[1]) - 0.5f);
     F3 ps = {fmaf(fy, cam.dv[0], fmaf(fx, cam.du[0], cam.p00[0])), fmaf(fy, cam.dv[1], fmaf(fx, cam.du[1], cam.p00[1])),
              fmaf(fy, cam.dv[2], fmaf(fx, cam.du[2], cam.p00[2]))};
@@ -473,6 +473,22 @@ __device__ __forceinline__ void render_f32_body() {
         }
     };
 
+    // adds one finished sample's colour to its pixel (colors.rs:38): the wave's LDS slot, or memory if the pixel has
+    // left the cache
+    auto deposit = [&](float cr, float cg, float cb, uint32_t pixel_word, uint32_t slot) {
+        const unsigned long long fr = to_fixed(cr), fg = to_fixed(cg), fb = to_fixed(cb);
+        if (__hip_atomic_load(&lds_tag[wv][slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == pixel_word) {
+            __hip_atomic_fetch_add(&lds_sum[wv][slot][0], fr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(&lds_sum[wv][slot][1], fg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(&lds_sum[wv][slot][2], fb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else {
+            const uint32_t at = partition_index(pixel_word), npix = pixel_count();
+            atomicAdd(&a->accum[at], fr);
+            atomicAdd(&a->accum[(size_t)npix + at], fg);
+            atomicAdd(&a->accum[2 * (size_t)npix + at], fb);
+        }
+    };
+
     // per-lane path state
     uint32_t gpix = 0u; // Philox pixel word j * W + i of the lane's sample
     uint32_t ss = 0u;   // sample index within the call (24 bits) | cache slot << 24
@@ -481,6 +497,7 @@ __device__ __forceinline__ void render_f32_body() {
     PathRay ray = {{0.f, 0.f, 0.f}, {0.f, 0.f, 1.f}, 0.001f};
     F3 thr = {1.f, 1.f, 1.f};
     bool fresh = false;   // the ray has not been intersected yet
+    bool camera = false;  // a sample has been taken and its camera ray is still to be made
     bool walking = false; // grid scan: the lane is on its way through the grid
     ScanBest sb = {INFINITY, -1, false};
     Walk walk = {};
@@ -497,91 +514,6 @@ __device__ __forceinline__ void render_f32_body() {
 
     for (;;) {
         a = opaque(a);
-        // ---- refill: camera.rs:217-224 ------------------------------------------------------------
-        bool need = stage == 0;
-        unsigned long long want = __ballot(need);
-        while (want != 0ull) {
-            const uint32_t W = (uint32_t)a->cam.W, spp = (uint32_t)a->cam.spp;
-            // at least one sample per lane in a pixel and rows longer than a pool: a hand-out wraps at most once
-            // (not in the grid kernel: it has no register to spare, and the walk dwarfs the two divisions)
-            const bool stepwise = SCAN != kScanGrid && spp >= 64u && W >= (uint32_t)kSlots;
-            if (pool_q == pool_n && !exhausted) { // open the next pool
-                const uint32_t npix = pixel_count(), pixels_per_pool = (uint32_t)a->pixels_per_pool;
-                if (grab_next == grab_end) {
-                    // One returning atomic on the global pixel counter grabs pixels for several pools: the counter
-                    // sustains only ~80 M returning atomics per second (a 100-spp frame with one atomic per pixel
-                    // was bound by exactly that), so a grab covers several pools (plan_render_f32 sizes it).  Grabs shrink as the
-                    // queue drains (half the remaining pixels spread over all waves), which keeps the last waves'
-                    // tail short.
-                    unsigned long long base = 0ull;
-                    if (lane == 0) base = atomicAdd(&a->counters->next_item, (unsigned long long)grab_pixels);
-                    const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)base, 0);
-                    const uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(base >> 32), 0);
-                    if (hi != 0u || lo >= npix) {
-                        exhausted = true;
-                    } else {
-                        grab_next = lo;
-                        grab_end = lo + min(grab_pixels, npix - lo);
-                        const uint32_t fair = (npix - grab_end) / (2u * gridDim.x * (blockDim.x >> 6));
-                        grab_pixels = max(pixels_per_pool, min((uint32_t)a->grab_pixels, fair));
-                    }
-                }
-                if (!exhausted) {
-                    const uint32_t lo = grab_next;
-                    pool_slot = (pool_slot + pool_pixels) & (uint32_t)(kSlots - 1);
-                    pool_pixels = min(pixels_per_pool, grab_end - lo);
-                    grab_next = lo + pool_pixels;
-                    pool_pix = lo;
-                    pool_r0 = lo / W;
-                    pool_i0 = lo - pool_r0 * W;
-                    pool_q = pool_dp = pool_smp = 0u;
-                    pool_n = pool_pixels * spp;
-                    n_samples += (unsigned long long)pool_n;
-                    retire_slots(pool_slot, lo, pool_pixels, true);
-                }
-            }
-            if (exhausted) { // every idle lane gets here once the queue is empty: the wave then drains and exits
-                if (need) stage = -1;
-                break;
-            }
-            const uint32_t avail = pool_n - pool_q;
-            const uint32_t wanted = (uint32_t)__popcll(want);
-            const uint32_t take = wanted < avail ? wanted : avail;
-            const uint32_t rank = (uint32_t)__popcll(want & ((1ull << lane) - 1ull));
-            if (need && rank < take) {
-                // the lane's place in the pool: pixel `dp` places after the pool's first, sample `smp` of it
-                uint32_t dp, smp, r, i;
-                if (stepwise) { // one conditional step each instead of two integer divisions per hand-out
-                    smp = pool_smp + rank;
-                    dp = pool_dp;
-                    if (smp >= spp) { smp -= spp; dp++; }
-                    i = pool_i0 + dp;
-                    r = pool_r0;
-                    if (i >= W) { i -= W; r++; }
-                } else {
-                    const uint32_t q = pool_q + rank;
-                    dp = q / spp;
-                    smp = q - dp * spp;
-                    const uint32_t pix = pool_pix + dp;
-                    r = pix / W;
-                    i = pix - r * W;
-                }
-                const int32_t pi = (int32_t)i, pj = a->part.row_begin + (int32_t)r * a->part.row_step;
-                gpix = (uint32_t)pj * W + (uint32_t)pi;
-                ss = smp | (((pool_slot + dp) & (uint32_t)(kSlots - 1)) << 24);
-                const Stream st = {a->key.k0, a->key.k1, gpix, a->key.sample_offset + smp, 0u};
-                camera_ray(&a->cam, pi, pj, st, ray);
-                thr = {1.f, 1.f, 1.f};
-                stage = 1;
-                fresh = true;
-                need = false;
-            }
-            pool_q += take;
-            pool_smp += take;
-            if (pool_smp >= spp) { pool_smp -= spp; pool_dp++; } // only read when stepwise
-            want = __ballot(need);
-        }
-        if (__ballot(stage > 0) == 0ull) break;
 
         // ---- closest hit over the sphere list: hittable_list.rs:60-74 ---------------------------
         if (fresh) {
@@ -677,87 +609,170 @@ __device__ __forceinline__ void render_f32_body() {
             }
         }
 
-        // ---- the scatter's uniforms, drawn by the whole wave --------------------------------------
-        // Every scatter that draws at all starts with block 0 of its stage (Lambertian and Metal: first
-        // unit-vector attempt; Dialectric: the reflect/refract uniform).  The further attempts of the rejection
-        // sampler are shared out over all 64 lanes, shading or not (coop_unit_vector).
-        const bool wants_vector = mk == DRAY_MAT_LAMBERTIAN || mk == DRAY_MAT_METAL;
-        const Stream st = {a->key.k0, a->key.k1, gpix, a->key.sample_offset + (ss & 0xFFFFFFu), (uint32_t)stage};
+        // ---- paths that end here without scattering: sky (camera.rs:279-281), an absorbing material
+        // (material.rs:13-19), or no depth left for the scattered ray (camera.rs:265-267: its colour is 0) ------
+        const bool ends_now = shading && (bidx < 0 || mk == DRAY_MAT_DEFAULT || stage >= a->cam.max_depth);
+        if (ends_now) {
+            if (bidx < 0) {
+                const float ta = 0.5f * (ray.d.y + 1.0f);
+                const float tw = 1.0f - ta;
+                deposit(thr.x * fmaf(ta, 0.5f, tw), thr.y * fmaf(ta, 0.7f, tw), thr.z * fmaf(ta, 1.0f, tw), gpix, ss >> 24);
+            } // else the sample's colour is zero: nothing to add (colors.rs:38)
+            stage = 0;
+        }
+
+        // ---- refill: camera.rs:217-224.  Idle lanes (their path just ended, or the launch just began) take the
+        // pool's next samples; their camera ray is made further down, so that its first Philox block is evaluated
+        // together with the scattering lanes' first block ----------------------------------------------
+        bool need = stage == 0 && !camera;
+        unsigned long long want = __ballot(need);
+        while (want != 0ull) {
+            const uint32_t W = (uint32_t)a->cam.W, spp = (uint32_t)a->cam.spp;
+            // at least one sample per lane in a pixel and rows longer than a pool: a hand-out wraps at most once
+            // (not in the grid kernel: it has no register to spare, and the walk dwarfs the two divisions)
+            const bool stepwise = SCAN != kScanGrid && spp >= 64u && W >= (uint32_t)kSlots;
+            if (pool_q == pool_n && !exhausted) { // open the next pool
+                const uint32_t npix = pixel_count(), pixels_per_pool = (uint32_t)a->pixels_per_pool;
+                if (grab_next == grab_end) {
+                    // One returning atomic on the global pixel counter grabs pixels for several pools: the counter
+                    // sustains only ~80 M returning atomics per second (a 100-spp frame with one atomic per pixel
+                    // was bound by exactly that), so a grab covers several pools (plan_render_f32 sizes it).  Grabs shrink as the
+                    // queue drains (half the remaining pixels spread over all waves), which keeps the last waves'
+                    // tail short.
+                    unsigned long long base = 0ull;
+                    if (lane == 0) base = atomicAdd(&a->counters->next_item, (unsigned long long)grab_pixels);
+                    const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)base, 0);
+                    const uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(base >> 32), 0);
+                    if (hi != 0u || lo >= npix) {
+                        exhausted = true;
+                    } else {
+                        grab_next = lo;
+                        grab_end = lo + min(grab_pixels, npix - lo);
+                        const uint32_t fair = (npix - grab_end) / (2u * gridDim.x * (blockDim.x >> 6));
+                        grab_pixels = max(pixels_per_pool, min((uint32_t)a->grab_pixels, fair));
+                    }
+                }
+                if (!exhausted) {
+                    const uint32_t lo = grab_next;
+                    pool_slot = (pool_slot + pool_pixels) & (uint32_t)(kSlots - 1);
+                    pool_pixels = min(pixels_per_pool, grab_end - lo);
+                    grab_next = lo + pool_pixels;
+                    pool_pix = lo;
+                    pool_r0 = lo / W;
+                    pool_i0 = lo - pool_r0 * W;
+                    pool_q = pool_dp = pool_smp = 0u;
+                    pool_n = pool_pixels * spp;
+                    n_samples += (unsigned long long)pool_n;
+                    retire_slots(pool_slot, lo, pool_pixels, true);
+                }
+            }
+            if (exhausted) { // every idle lane gets here once the queue is empty: the wave then drains and exits
+                if (need) stage = -1;
+                break;
+            }
+            const uint32_t avail = pool_n - pool_q;
+            const uint32_t wanted = (uint32_t)__popcll(want);
+            const uint32_t take = wanted < avail ? wanted : avail;
+            const uint32_t rank = (uint32_t)__popcll(want & ((1ull << lane) - 1ull));
+            if (need && rank < take) {
+                // the lane's place in the pool: pixel `dp` places after the pool's first, sample `smp` of it
+                uint32_t dp, smp, r, i;
+                if (stepwise) { // one conditional step each instead of two integer divisions per hand-out
+                    smp = pool_smp + rank;
+                    dp = pool_dp;
+                    if (smp >= spp) { smp -= spp; dp++; }
+                    i = pool_i0 + dp;
+                    r = pool_r0;
+                    if (i >= W) { i -= W; r++; }
+                } else {
+                    const uint32_t q = pool_q + rank;
+                    dp = q / spp;
+                    smp = q - dp * spp;
+                    const uint32_t pix = pool_pix + dp;
+                    r = pix / W;
+                    i = pix - r * W;
+                }
+                const int32_t pi = (int32_t)i, pj = a->part.row_begin + (int32_t)r * a->part.row_step;
+                gpix = (uint32_t)pj * W + (uint32_t)pi;
+                ss = smp | (((pool_slot + dp) & (uint32_t)(kSlots - 1)) << 24);
+                ray.o = {(float)pi, (float)pj, 0.f}; // exact; the camera step below turns them into the ray
+                camera = true;
+                need = false;
+            }
+            pool_q += take;
+            pool_smp += take;
+            if (pool_smp >= spp) { pool_smp -= spp; pool_dp++; } // only read when stepwise
+            want = __ballot(need);
+        }
+        if (__ballot(stage > 0 || camera) == 0ull) break;
+
+        // ---- first uniforms of the lane's next step, drawn by the whole wave ---------------------------
+        // A scattering lane starts with block 0 of its stage (Lambertian and Metal: first unit-vector attempt;
+        // Dialectric: the reflect/refract uniform), a lane with a new sample with block 0 of stage 0 (pixel offsets,
+        // first aperture attempt): one evaluation serves both.  The further attempts of the unit-vector rejection
+        // sampler are shared out over all 64 lanes, busy or not (coop_unit_vector).
+        const bool scatters = shading && !ends_now;
+        const bool wants_vector = scatters && (mk == DRAY_MAT_LAMBERTIAN || mk == DRAY_MAT_METAL);
+        const Stream st = {a->key.k0, a->key.k1, gpix, a->key.sample_offset + (ss & 0xFFFFFFu),
+                           camera ? 0u : (uint32_t)stage};
         uint32_t w[4] = {0u, 0u, 0u, 0u};
-        if (wants_vector || mk == DRAY_MAT_DIELECTRIC) st.block(0, w);
+        if (camera || scatters) st.block(0, w);
         // drawn even when a metal's fuzz is 0 (material.rs:75)
         const F3 ruv = coop_unit_vector(st, w, wants_vector, lds_req[wv], lane);
 
-        // ---- shade: camera.rs:270-281 -------------------------------------------------------------
-        if (shading) {
+        // ---- scatter: material.rs ---------------------------------------------------------------------
+        if (scatters) {
             const float dx = ray.d.x, dy = ray.d.y, dz = ray.d.z;
-            F3 c = {0.f, 0.f, 0.f};
-            bool ended = true;
-            if (bidx < 0) { // sky
-                const float ta = 0.5f * (dy + 1.0f);
-                const float tw = 1.0f - ta;
-                c = {thr.x * fmaf(ta, 0.5f, tw), thr.y * fmaf(ta, 0.7f, tw), thr.z * fmaf(ta, 1.0f, tw)};
-            } else {
-                const bool front = dot(ray.d, hn) < 0.f; // hittable.rs:16-22
-                const F3 n = front ? hn : F3{-hn.x, -hn.y, -hn.z};
-                F3 nd = {0.f, 0.f, 0.f};
-                bool scattered = false;
-                if (mk == DRAY_MAT_LAMBERTIAN) { // material.rs:46-56
-                    nd = n + ruv;
-                    if (fabsf(nd.x) < 1e-8f && fabsf(nd.y) < 1e-8f && fabsf(nd.z) < 1e-8f) nd = n;
-                    thr = {thr.x * m.x, thr.y * m.y, thr.z * m.z};
-                    scattered = true;
-                } else if (mk == DRAY_MAT_METAL) { // material.rs:73-80; reflect(d, n) is already unit
-                    const float dn = dot(ray.d, n);
-                    const F3 refl = {fmaf(-2.f * dn, n.x, dx), fmaf(-2.f * dn, n.y, dy), fmaf(-2.f * dn, n.z, dz)};
-                    nd = {fmaf(m.w, ruv.x, refl.x), fmaf(m.w, ruv.y, refl.y), fmaf(m.w, ruv.z, refl.z)};
-                    thr = {thr.x * m.x, thr.y * m.y, thr.z * m.z};
-                    scattered = dot(nd, n) > 0.f;
-                } else if (mk == DRAY_MAT_DIELECTRIC) { // material.rs:103-122
-                    const float ri = front ? rcp(m.w) : m.w;
-                    const float cos_theta = fminf(-dot(ray.d, n), 1.0f);
-                    const float sin_theta = fsqrt(fmaxf(fmaf(-cos_theta, cos_theta, 1.0f), 0.f));
-                    bool reflects = ri * sin_theta > 1.0f;
-                    if (!reflects) { // the uniform counts only when refraction is possible (material.rs:114)
-                        float r0 = (1.f - ri) * rcp(1.f + ri);
-                        r0 = r0 * r0;
-                        const float x = 1.f - cos_theta, x2 = x * x;
-                        reflects = fmaf(1.f - r0, x * x2 * x2, r0) > u01<float>(w[0]);
-                    }
-                    if (reflects) { // vec3.rs:97-102
-                        nd = {fmaf(2.f * cos_theta, n.x, dx), fmaf(2.f * cos_theta, n.y, dy), fmaf(2.f * cos_theta, n.z, dz)};
-                    } else { // vec3.rs:104-109
-                        const F3 perp = {ri * fmaf(cos_theta, n.x, dx), ri * fmaf(cos_theta, n.y, dy), ri * fmaf(cos_theta, n.z, dz)};
-                        const float kpar = -fsqrt(fabsf(1.0f - dot(perp, perp)));
-                        nd = {fmaf(kpar, n.x, perp.x), fmaf(kpar, n.y, perp.y), fmaf(kpar, n.z, perp.z)};
-                    }
-                    scattered = true;
+            const bool front = dot(ray.d, hn) < 0.f; // hittable.rs:16-22
+            const F3 n = front ? hn : F3{-hn.x, -hn.y, -hn.z};
+            F3 nd = {0.f, 0.f, 0.f};
+            bool scattered = true;
+            if (mk == DRAY_MAT_LAMBERTIAN) { // material.rs:46-56
+                nd = n + ruv;
+                if (fabsf(nd.x) < 1e-8f && fabsf(nd.y) < 1e-8f && fabsf(nd.z) < 1e-8f) nd = n;
+                thr = {thr.x * m.x, thr.y * m.y, thr.z * m.z};
+            } else if (mk == DRAY_MAT_METAL) { // material.rs:73-80; reflect(d, n) is already unit
+                const float dn = dot(ray.d, n);
+                const F3 refl = {fmaf(-2.f * dn, n.x, dx), fmaf(-2.f * dn, n.y, dy), fmaf(-2.f * dn, n.z, dz)};
+                nd = {fmaf(m.w, ruv.x, refl.x), fmaf(m.w, ruv.y, refl.y), fmaf(m.w, ruv.z, refl.z)};
+                thr = {thr.x * m.x, thr.y * m.y, thr.z * m.z};
+                scattered = dot(nd, n) > 0.f;
+            } else { // Dialectric, material.rs:103-122
+                const float ri = front ? rcp(m.w) : m.w;
+                const float cos_theta = fminf(-dot(ray.d, n), 1.0f);
+                const float sin_theta = fsqrt(fmaxf(fmaf(-cos_theta, cos_theta, 1.0f), 0.f));
+                bool reflects = ri * sin_theta > 1.0f;
+                if (!reflects) { // the uniform counts only when refraction is possible (material.rs:114)
+                    float r0 = (1.f - ri) * rcp(1.f + ri);
+                    r0 = r0 * r0;
+                    const float x = 1.f - cos_theta, x2 = x * x;
+                    reflects = fmaf(1.f - r0, x * x2 * x2, r0) > u01<float>(w[0]);
                 }
-                if (scattered) {
-                    stage++;
-                    if (stage <= a->cam.max_depth) { // camera.rs:265: the next call would still have depth > 0
-                        ray.o = hp;
-                        set_dir(ray, nd);
-                        fresh = true;
-                        ended = false;
-                    }
+                if (reflects) { // vec3.rs:97-102
+                    nd = {fmaf(2.f * cos_theta, n.x, dx), fmaf(2.f * cos_theta, n.y, dy), fmaf(2.f * cos_theta, n.z, dz)};
+                } else { // vec3.rs:104-109
+                    const F3 perp = {ri * fmaf(cos_theta, n.x, dx), ri * fmaf(cos_theta, n.y, dy), ri * fmaf(cos_theta, n.z, dz)};
+                    const float kpar = -fsqrt(fabsf(1.0f - dot(perp, perp)));
+                    nd = {fmaf(kpar, n.x, perp.x), fmaf(kpar, n.y, perp.y), fmaf(kpar, n.z, perp.z)};
                 }
             }
-            if (ended) { // colors.rs:38
-                const unsigned long long fr = to_fixed(c.x), fg = to_fixed(c.y), fb = to_fixed(c.z);
-                const uint32_t slot = ss >> 24;
-                if (__hip_atomic_load(&lds_tag[wv][slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == gpix) {
-                    __hip_atomic_fetch_add(&lds_sum[wv][slot][0], fr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    __hip_atomic_fetch_add(&lds_sum[wv][slot][1], fg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    __hip_atomic_fetch_add(&lds_sum[wv][slot][2], fb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                } else {
-                    const uint32_t at = partition_index(gpix), npix = pixel_count();
-                    atomicAdd(&a->accum[at], fr);
-                    atomicAdd(&a->accum[(size_t)npix + at], fg);
-                    atomicAdd(&a->accum[2 * (size_t)npix + at], fb);
-                }
+            if (scattered) { // camera.rs:271-274; depth is left for the next segment (see ends_now)
+                stage++;
+                ray.o = hp;
+                set_dir(ray, nd);
+                fresh = true;
+            } else { // absorbed (camera.rs:276): the sample's colour is zero, nothing to add; idle until the next refill
                 stage = 0;
             }
+        }
+
+        // ---- camera ray of a new sample: camera.rs:238-262 --------------------------------------------
+        if (camera) {
+            camera_ray(&a->cam, (int32_t)ray.o.x, (int32_t)ray.o.y, st, w, ray);
+            thr = {1.f, 1.f, 1.f};
+            stage = 1;
+            fresh = true;
+            camera = false;
         }
     }
 
