@@ -85,28 +85,40 @@ __device__ __forceinline__ bool unit_vector_attempt(const uint32_t (&w)[4], F3& 
     return (1e-30f <= l2) & (l2 <= 1.f);
 }
 
-// The rejection sampler for all lanes of a wave at once.  Called by all 64 lanes (wave-uniform control flow);
-// `want` marks the lanes that need a vector and `w` holds block 0 of their stage.  A lane accepts an attempt with
-// probability pi/6, so run lane by lane the wave would spend the MAXIMUM attempt count over its lanes (about six
-// Philox blocks) with most lanes idle.  Instead, after every lane's own attempt 0, the lanes still pending hand
-// their stream to k = 1, 2, 4 or 8 server lanes each (k * pending <= 64), which evaluate the next k attempts in
-// parallel; the pending lane takes the accepted attempt with the smallest index.  Same streams, same attempts,
-// same winner as the sequential loop -- in about three rounds.  Requests travel through the wave's `req` slots in
-// LDS (LDS keeps one wave's accesses in order), results through lane permutes.
-__device__ __forceinline__ F3 coop_unit_vector(const Stream& st, const uint32_t (&w)[4], bool want, uint4* req, int lane) {
+// vec3.rs:111-118: rejection sampling in the square; an aperture attempt is two consecutive uniforms.
+__device__ __forceinline__ bool unit_disk_attempt(uint32_t wx, uint32_t wy, float& px, float& py) {
+    px = fmaf(2.f, u01<float>(wx), -1.f);
+    py = fmaf(2.f, u01<float>(wy), -1.f);
+    return fmaf(px, px, py * py) < 1.f;
+}
+
+enum { kDrawNone = 0, kDrawUnitVector = 1, kDrawUnitDisk = 2 };
+
+// The two rejection samplers of the path for all lanes of a wave at once.  Called by all 64 lanes (wave-uniform
+// control flow).  `draw` says what the lane needs: a unit vector for its scatter (attempt a = words 0..2 of block a
+// of its stage), a point in the unit disk for its new sample's aperture (attempt m = uniforms 2+2m, 3+2m of stage
+// 0, i.e. the second half of block 0, then two attempts per block), or nothing.  `w` holds block 0 of the lane's
+// stream.  A unit-vector attempt succeeds with probability pi/6, so run lane by lane the wave would spend the
+// MAXIMUM attempt count over its lanes (about six Philox blocks) with most lanes idle.  Instead, after every
+// lane's own first attempt, the lanes still pending hand their stream to k = 1, 2, 4 or 8 server lanes each
+// (k * pending <= 64), which evaluate the next k blocks in parallel; the pending lane takes the accepted attempt
+// with the smallest index.  Same streams, same attempts, same winner as the sequential loops -- in about three
+// rounds.  Requests travel through the wave's `req` slots in LDS (LDS keeps one wave's accesses in order),
+// results through lane permutes.  Returns the unit vector, or the disk point in x, y.
+__device__ __forceinline__ F3 coop_draw(const Stream& st, const uint32_t (&w)[4], uint32_t draw, uint4* req, int lane) {
     F3 res = {0.f, 0.f, 0.f};
     bool pending = false;
-    if (want) {
-        F3 v;
-        pending = !unit_vector_attempt(w, v);
-        res = v;
+    if (draw == kDrawUnitVector) {
+        pending = !unit_vector_attempt(w, res);
+    } else if (draw == kDrawUnitDisk) {
+        pending = !unit_disk_attempt(w[2], w[3], res.x, res.y);
     }
-    uint32_t base = 1u; // next attempt index, the same for every pending lane
+    uint32_t base = 1u; // next block index, the same for every pending lane
     for (unsigned long long pm = __ballot(pending); pm != 0ull; pm = __ballot(pending)) {
         const uint32_t n_pending = (uint32_t)__popcll(pm);
         const uint32_t shift = n_pending <= 8u ? 3u : n_pending <= 16u ? 2u : n_pending <= 32u ? 1u : 0u; // log2 k
         const uint32_t rank = (uint32_t)__popcll(pm & ((1ull << lane) - 1ull));
-        if (pending) req[rank] = make_uint4(st.pixel, st.sample, st.stage, 0u);
+        if (pending) req[rank] = make_uint4(st.pixel, st.sample, st.stage, draw);
         const uint32_t served = (uint32_t)lane >> shift; // rank of the pending lane this lane serves
         const bool serving = served < n_pending;
         const uint4 r = req[serving ? served : 0u];
@@ -114,7 +126,12 @@ __device__ __forceinline__ F3 coop_unit_vector(const Stream& st, const uint32_t 
         uint32_t wb[4];
         other.block(base + ((uint32_t)lane & ((1u << shift) - 1u)), wb);
         F3 v;
-        const bool ok = unit_vector_attempt(wb, v) & serving;
+        const bool ok_vector = unit_vector_attempt(wb, v);
+        float ax, ay, bx, by;
+        const bool ok_a = unit_disk_attempt(wb[0], wb[1], ax, ay), ok_b = unit_disk_attempt(wb[2], wb[3], bx, by);
+        const bool disk = r.w == kDrawUnitDisk;
+        if (disk) v = {ok_a ? ax : bx, ok_a ? ay : by, 0.f};
+        const bool ok = serving & (disk ? (ok_a | ok_b) : ok_vector);
         const unsigned long long okm = __ballot(ok);
         const uint32_t mine = (uint32_t)(okm >> (rank << shift)) & ((1u << (1u << shift)) - 1u); // my servers' verdicts
         const bool got = pending & (mine != 0u);
@@ -141,28 +158,19 @@ __device__ __forceinline__ void set_dir(PathRay& r, F3 dir) {
     r.tmin = 0.001f * (l2 * inv);
 }
 
-// camera.rs:238-262
-// `w` holds block 0 of the sample's stage-0 stream on entry.
-__device__ __forceinline__ void camera_ray(ConstPtr<CamDev<float>> camp, int32_t i, int32_t j, const Stream& st,
-                                           uint32_t (&w)[4], PathRay& r) {
+// camera.rs:238-262.  `w` holds block 0 of the sample's stage-0 stream (uniforms 0, 1: the offsets in the pixel);
+// `disk` is the accepted aperture sample (vec3.rs:111-118), drawn by coop_draw.
+__device__ __forceinline__ void camera_ray(ConstPtr<CamDev<float>> camp, int32_t i, int32_t j, const uint32_t (&w)[4],
+                                           F3 disk, PathRay& r) {
     const DRAY_CONSTANT CamDev<float>& cam = *camp;
     const float fx = (float)i + (u01<float>(w[0]) - 0.5f), fy = (float)j + (u01<float>(w[1]) - 0.5f);
     F3 ps = {fmaf(fy, cam.dv[0], fmaf(fx, cam.du[0], cam.p00[0])), fmaf(fy, cam.dv[1], fmaf(fx, cam.du[1], cam.p00[1])),
              fmaf(fy, cam.dv[2], fmaf(fx, cam.du[2], cam.p00[2]))};
     F3 o = {cam.center[0], cam.center[1], cam.center[2]};
     if (cam.defocus) {
-        float px, py;
-        for (uint32_t m = 0;; ++m) { // vec3.rs:111-118; attempt m = uniforms 2+2m, 3+2m
-            const uint32_t d0 = 2u + 2u * m;
-            if (m > 0 && (d0 & 3u) == 0u) st.block(d0 >> 2, w);
-            const bool hi = (d0 & 3u) != 0u;
-            px = fmaf(2.f, u01<float>(hi ? w[2] : w[0]), -1.f);
-            py = fmaf(2.f, u01<float>(hi ? w[3] : w[1]), -1.f);
-            if (fmaf(px, px, py * py) < 1.f) break;
-        }
-        o.x = fmaf(py, cam.ddv[0], fmaf(px, cam.ddu[0], o.x));
-        o.y = fmaf(py, cam.ddv[1], fmaf(px, cam.ddu[1], o.y));
-        o.z = fmaf(py, cam.ddv[2], fmaf(px, cam.ddu[2], o.z));
+        o.x = fmaf(disk.y, cam.ddv[0], fmaf(disk.x, cam.ddu[0], o.x));
+        o.y = fmaf(disk.y, cam.ddv[1], fmaf(disk.x, cam.ddu[1], o.y));
+        o.z = fmaf(disk.y, cam.ddv[2], fmaf(disk.x, cam.ddu[2], o.z));
     }
     r.o = o;
     set_dir(r, ps - o);
@@ -436,7 +444,7 @@ __device__ __forceinline__ void render_f32_body() {
     // one wave's accesses in order, and tags and sums are only ever touched by their own wave: no barrier.
     __shared__ unsigned long long lds_sum[4][kSlots][3]; // [wave of the block][slot][r, g, b]
     __shared__ uint32_t lds_tag[4][kSlots];              // the slot's pixel: its Philox pixel word (j * W + i)
-    __shared__ uint4 lds_req[4][64];                     // coop_unit_vector: streams handed to server lanes
+    __shared__ uint4 lds_req[4][64];                     // coop_draw: streams handed to server lanes
     const int wv = (int)(threadIdx.x >> 6);
     if (lane < kSlots) {
         __hip_atomic_store(&lds_tag[wv][lane], kNoPixel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -710,15 +718,18 @@ __device__ __forceinline__ void render_f32_body() {
         // A scattering lane starts with block 0 of its stage (Lambertian and Metal: first unit-vector attempt;
         // Dialectric: the reflect/refract uniform), a lane with a new sample with block 0 of stage 0 (pixel offsets,
         // first aperture attempt): one evaluation serves both.  The further attempts of the unit-vector rejection
-        // sampler are shared out over all 64 lanes, busy or not (coop_unit_vector).
+        // sampler, and of the aperture's, are shared out over all 64 lanes, busy or not (coop_draw).
         const bool scatters = shading && !ends_now;
         const bool wants_vector = scatters && (mk == DRAY_MAT_LAMBERTIAN || mk == DRAY_MAT_METAL);
         const Stream st = {a->key.k0, a->key.k1, gpix, a->key.sample_offset + (ss & 0xFFFFFFu),
                            camera ? 0u : (uint32_t)stage};
         uint32_t w[4] = {0u, 0u, 0u, 0u};
         if (camera || scatters) st.block(0, w);
-        // drawn even when a metal's fuzz is 0 (material.rs:75)
-        const F3 ruv = coop_unit_vector(st, w, wants_vector, lds_req[wv], lane);
+        // the unit vector is drawn even when a metal's fuzz is 0 (material.rs:75); the aperture sample only with
+        // defocus_angle > 0 (camera.rs:247)
+        const uint32_t draw = wants_vector ? (uint32_t)kDrawUnitVector
+                                           : (camera && a->cam.defocus != 0) ? (uint32_t)kDrawUnitDisk : (uint32_t)kDrawNone;
+        const F3 ruv = coop_draw(st, w, draw, lds_req[wv], lane);
 
         // ---- scatter: material.rs ---------------------------------------------------------------------
         if (scatters) {
@@ -768,7 +779,7 @@ __device__ __forceinline__ void render_f32_body() {
 
         // ---- camera ray of a new sample: camera.rs:238-262 --------------------------------------------
         if (camera) {
-            camera_ray(&a->cam, (int32_t)ray.o.x, (int32_t)ray.o.y, st, w, ray);
+            camera_ray(&a->cam, (int32_t)ray.o.x, (int32_t)ray.o.y, w, ruv, ray);
             thr = {1.f, 1.f, 1.f};
             stage = 1;
             fresh = true;
