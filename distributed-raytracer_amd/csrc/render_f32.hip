@@ -501,7 +501,7 @@ __device__ __forceinline__ void render_f32_body() {
     uint32_t gpix = 0u; // Philox pixel word j * W + i of the lane's sample
     uint32_t ss = 0u;   // sample index within the call (24 bits) | cache slot << 24
     int32_t stage = 0;  // 0: idle, k > 0: on the k-th segment of a path, < 0: the queue has run out
-    uint32_t n_seg = 0;
+    unsigned long long n_seg = 0ull; // segments of this wave, counted on the scalar unit from the lane mask
     PathRay ray = {{0.f, 0.f, 0.f}, {0.f, 0.f, 1.f}, 0.001f};
     F3 thr = {1.f, 1.f, 1.f};
     bool fresh = false;   // the ray has not been intersected yet
@@ -524,8 +524,8 @@ __device__ __forceinline__ void render_f32_body() {
         a = opaque(a);
 
         // ---- closest hit over the sphere list: hittable_list.rs:60-74 ---------------------------
+        n_seg += (unsigned long long)__popcll(__ballot(fresh));
         if (fresh) {
-            n_seg++;
             sb = {INFINITY, -1, false};
             if constexpr (SCAN == kScanHybrid)
                 scan_hybrid(lds_xy, as_constant(a->filter_zn), as_constant(a->narrow_geom), a->n_narrow_padded, ray, sb);
@@ -789,10 +789,8 @@ __device__ __forceinline__ void render_f32_body() {
 
     retire_slots(0u, 0u, (uint32_t)kSlots, false);
 
-    unsigned long long segs = n_seg;
-    for (int off = 32; off > 0; off >>= 1) segs += __shfl_down(segs, off, 64);
     if (lane == 0) {
-        atomicAdd(&a->counters->segments, segs);
+        atomicAdd(&a->counters->segments, n_seg);
         atomicAdd(&a->counters->samples, n_samples);
         if constexpr (SCAN == kScanGrid) atomicAdd(&a->counters->walk_steps, (unsigned long long)n_steps);
     }
