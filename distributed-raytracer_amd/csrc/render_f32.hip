@@ -273,11 +273,10 @@ constexpr int kScanScalar = DRAY_SCAN_SCALAR, kScanHybrid = DRAY_SCAN_HYBRID, kS
 // A lane's walk survives the kernel's main loop: lanes whose walk is over are shaded and given their next ray
 // while the long walks of other lanes go on, instead of the whole wave waiting for its longest walk.
 struct Walk {
-    float A[3], B[3]; // time at which the ray reaches plane k of an axis: fma(k, A, B)
-    float slack;      // bound on the rounding error of those times
-    int32_t c[3];     // current cell
-    uint32_t ci;      // its index in the cell table
-    uint32_t ahead;   // bit a: the ray moves towards larger indices on axis a
+    // time at which the ray leaves cell k of an axis: fma(k, A, B); A = cell / d, B = (lo - o + [d >= 0] cell) / d
+    float A[3], B[3];
+    float slack;       // bound on the rounding error of those times
+    float c[3];        // current cell (small integers, exact in f32)
     uint32_t e, e_end; // entries of the current cell still to test
     // Closest accepted root so far as one ordered key: bits of t (positive floats order like integers) in the high
     // word, then the sphere's narrow position and the far-root flag.  The minimum key is the scalar scan's answer:
@@ -315,18 +314,16 @@ __device__ __forceinline__ bool walk_begin(ConstPtr<GridDev> gp, ConstPtr<V4> na
     if (g.n[0] == 0) return false;
     const float o[3] = {ray.o.x, ray.o.y, ray.o.z}, d[3] = {ray.d.x, ray.d.y, ray.d.z};
     float t_in = 0.f, t_out = INFINITY, bmax = 0.f;
-    w.ahead = 0u;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-        if (d[a] >= 0.f) w.ahead |= 1u << a;
         if (fabsf(d[a]) > 1e-12f) {
             const float inv = rcp(d[a]);
             w.A[a] = g.cell[a] * inv;
-            w.B[a] = (g.lo[a] - o[a]) * inv;
-            const float t0 = w.B[a], t1 = (g.hi[a] - o[a]) * inv;
+            const float t0 = (g.lo[a] - o[a]) * inv, t1 = (g.hi[a] - o[a]) * inv;
+            w.B[a] = d[a] >= 0.f ? t0 + w.A[a] : t0; // leaving cell k towards larger indices happens at plane k + 1
             t_in = fmaxf(t_in, fminf(t0, t1));
             t_out = fminf(t_out, fmaxf(t0, t1));
-            bmax = fmaxf(bmax, fabsf(w.B[a]));
+            bmax = fmaxf(bmax, fmaxf(fabsf(t0), fabsf(w.B[a])));
         } else { // parallel to the axis' planes: never crosses one; misses the grid if outside its slab
             w.A[a] = 0.f;
             w.B[a] = INFINITY;
@@ -338,12 +335,12 @@ __device__ __forceinline__ bool walk_begin(ConstPtr<GridDev> gp, ConstPtr<V4> na
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         const float at = (fmaf(d[a], t_in, o[a]) - g.lo[a]) * g.inv_cell[a];
-        w.c[a] = min(max((int32_t)floorf(at), 0), g.n[a] - 1);
+        w.c[a] = fminf(fmaxf(floorf(at), 0.f), (float)(g.n[a] - 1));
     }
     w.e = w.e_end = 0u;
-    w.ci = (uint32_t)((w.c[2] * g.n[1] + w.c[1]) * g.n[0] + w.c[0]);
     if (walking) {
-        const uint2 rec = g.cells[w.ci];
+        const uint32_t ci = (uint32_t)fmaf(fmaf(w.c[2], (float)g.n[1], w.c[1]), (float)g.n[0], w.c[0]);
+        const uint2 rec = g.cells[ci];
         w.e = rec.x;
         w.e_end = rec.x + rec.y;
     }
@@ -352,7 +349,7 @@ __device__ __forceinline__ bool walk_begin(ConstPtr<GridDev> gp, ConstPtr<V4> na
 
 // What a step reads of the grid, held in scalar registers while a wave is stepping.
 struct GridRegs {
-    int32_t n0, n1, n2, n01;
+    float n0, n1, n2; // cells per axis (at most 256: products and sums below are exact in f32)
     const uint2* cells;
     const V4* entry_geom;
     const int32_t* entry_pos;
@@ -364,22 +361,22 @@ struct GridRegs {
 __device__ __forceinline__ bool walk_step(const GridRegs& g, const PathRay& ray, Walk& w) {
     bool go = true;
     if (w.e == w.e_end) { // this cell is done: stop, or step into the next one
-        const int32_t ax = (int32_t)(w.ahead & 1u), ay = (int32_t)((w.ahead >> 1) & 1u), az = (int32_t)((w.ahead >> 2) & 1u);
-        const float tx = fmaf((float)(w.c[0] + ax), w.A[0], w.B[0]);
-        const float ty = fmaf((float)(w.c[1] + ay), w.A[1], w.B[1]);
-        const float tz = fmaf((float)(w.c[2] + az), w.A[2], w.B[2]);
+        const float tx = fmaf(w.c[0], w.A[0], w.B[0]);
+        const float ty = fmaf(w.c[1], w.A[1], w.B[1]);
+        const float tz = fmaf(w.c[2], w.A[2], w.B[2]);
         const float t_exit = fminf(tx, fminf(ty, tz));
         const bool stop = __uint_as_float((uint32_t)(w.best >> 32)) < fmaf(t_exit, 1.f - 3.814697265625e-6f, -w.slack);
         const bool sx = (tx <= ty) & (tx <= tz);
         const bool sy = !sx & (ty <= tz);
-        w.c[0] += sx ? 2 * ax - 1 : 0;
-        w.c[1] += sy ? 2 * ay - 1 : 0;
-        w.c[2] += (sx | sy) ? 0 : 2 * az - 1;
-        w.ci += (uint32_t)(sx ? 2 * ax - 1 : (sy ? (2 * ay - 1) * g.n0 : (2 * az - 1) * g.n01));
-        const bool inside = ((uint32_t)w.c[0] < (uint32_t)g.n0) & ((uint32_t)w.c[1] < (uint32_t)g.n1) &
-                            ((uint32_t)w.c[2] < (uint32_t)g.n2);
+        // one step along the axis left first; A carries the direction's sign (a parallel axis is never chosen)
+        w.c[0] += sx ? copysignf(1.f, w.A[0]) : 0.f;
+        w.c[1] += sy ? copysignf(1.f, w.A[1]) : 0.f;
+        w.c[2] += (sx | sy) ? 0.f : copysignf(1.f, w.A[2]);
+        const float moved = sx ? w.c[0] : (sy ? w.c[1] : w.c[2]), limit = sx ? g.n0 : (sy ? g.n1 : g.n2);
+        const bool inside = (moved >= 0.f) & (moved < limit);
         go = inside & !stop;
-        const uint2 rec = g.cells[go ? w.ci : 0u];
+        const uint32_t ci = (uint32_t)fmaf(fmaf(w.c[2], g.n1, w.c[1]), g.n0, w.c[0]);
+        const uint2 rec = g.cells[go ? ci : 0u];
         w.e = rec.x;
         w.e_end = go ? rec.x + rec.y : rec.x;
     }
@@ -538,7 +535,7 @@ __device__ __forceinline__ void render_f32_body() {
         if constexpr (SCAN == kScanGrid) {
             // walk until fewer than a quorum of lanes are still on their way (all of them once the queue is empty)
             const int quorum = exhausted ? 1 : kWalkQuorum;
-            const GridRegs gr = {a->grid.n[0], a->grid.n[1], a->grid.n[2], a->grid.n[0] * a->grid.n[1], a->grid.cells,
+            const GridRegs gr = {(float)a->grid.n[0], (float)a->grid.n[1], (float)a->grid.n[2], a->grid.cells,
                                  (const V4*)a->grid.entry_geom, a->grid.entry_pos};
             do { // two steps per count: the count is scalar-unit work every walking lane waits for
                 if (walking) walking = walk_step(gr, ray, walk);
