@@ -634,8 +634,7 @@ __device__ __forceinline__ void render_f32_body() {
         while (want != 0ull) {
             const uint32_t W = (uint32_t)a->cam.W, spp = (uint32_t)a->cam.spp;
             // at least one sample per lane in a pixel and rows longer than a pool: a hand-out wraps at most once
-            // (not in the grid kernel: it has no register to spare, and the walk dwarfs the two divisions)
-            const bool stepwise = SCAN != kScanGrid && spp >= 64u && W >= (uint32_t)kSlots;
+            const bool stepwise = spp >= 64u && W >= (uint32_t)kSlots;
             if (pool_q == pool_n && !exhausted) { // open the next pool
                 const uint32_t npix = pixel_count(), pixels_per_pool = (uint32_t)a->pixels_per_pool;
                 if (grab_next == grab_end) {
