@@ -119,11 +119,17 @@ PATH_ENTRY_DTYPE = np.dtype(
      ("stage", "<u4"), ("px", PIXEL_INDEX_DTYPE), ("finished", "<u4"), ("hit_object_or_stop", "<u4"), ("_pad", "<u4")])
 assert PATH_ENTRY_DTYPE.itemsize == 128
 
+class GridInfo(C.Structure):
+    _fields_ = [("lo", C.c_double * 3), ("hi", C.c_double * 3), ("n", C.c_int32 * 3), ("n_narrow", C.c_int32),
+                ("n_wide", C.c_int32), ("n_loose", C.c_int32), ("n_entries", C.c_uint64),
+                ("max_cell_entries", C.c_uint32), ("_pad", C.c_uint32)]
+
+
 EXPORTS = (
     "dray_version", "dray_strerror", "dray_device_count", "dray_opts_default", "dray_camera_default",
     "dray_camera_initialize", "dray_render", "dray_scene_create", "dray_scene_destroy", "dray_render_device",
     "dray_scene_final", "dray_scene_recipe", "dray_scene_three_spheres", "dray_write_ppm", "dray_camera_rays",
-    "dray_path_step", "dray_camera_rays_device", "dray_path_step_device",
+    "dray_path_step", "dray_camera_rays_device", "dray_path_step_device", "dray_grid_inspect",
 )
 
 _lib = None
@@ -177,6 +183,7 @@ def lib():
     L.dray_path_step.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
     L.dray_camera_rays_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
     L.dray_path_step_device.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    L.dray_grid_inspect.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.dray_scene_recipe.argtypes = [C.c_uint64, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_void_p,
                                     C.c_size_t]
     _lib = L

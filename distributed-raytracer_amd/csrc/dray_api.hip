@@ -299,6 +299,52 @@ int upload(T** dst, const std::vector<T>& src) {
     return DRAY_OK;
 }
 
+// Splits the caller's list into the spheres the f32 kernel scans in f32 ("narrow": exact-table rows cx, cy, cz, r*r
+// and their positions in the caller's list) and those it intersects in f64 ("wide").
+void classify_spheres(const dray_sphere* sp, size_t n, std::vector<float>& ng, std::vector<int32_t>& nidx,
+                      std::vector<int32_t>& widx) {
+    for (size_t k = 0; k < n; ++k) {
+        const double r = std::fmax(sp[k].radius, 0.); // sphere.rs:14
+        if (r >= kWideRadius) {
+            widx.push_back((int32_t)k);
+        } else {
+            nidx.push_back((int32_t)k);
+            ng.push_back((float)sp[k].center[0]); ng.push_back((float)sp[k].center[1]); ng.push_back((float)sp[k].center[2]);
+            ng.push_back((float)(r * r));
+        }
+    }
+}
+
+int grid_inspect_impl(const dray_sphere* sp, size_t n, dray_grid_info* info, uint32_t* cell_begin, int32_t* entry_sphere,
+                      int32_t* loose_sphere) {
+    if (!info || (!sp && n) || n > 0x7fffffffu) return DRAY_ERR_INVALID_ARG;
+    std::vector<float> ng;
+    std::vector<int32_t> nidx, widx;
+    classify_spheres(sp, n, ng, nidx, widx);
+    GridHost g;
+    build_grid(ng, (int32_t)nidx.size(), g);
+    std::memset(info, 0, sizeof *info);
+    for (int a = 0; a < 3; ++a) {
+        info->lo[a] = g.dev.lo[a];
+        info->hi[a] = g.dev.hi[a];
+        info->n[a] = g.dev.n[a];
+    }
+    info->n_narrow = (int32_t)nidx.size();
+    info->n_wide = (int32_t)widx.size();
+    info->n_loose = (int32_t)g.loose.size();
+    info->n_entries = g.entry_pos.size();
+    for (size_t c = 0; c < g.cells.size(); ++c) {
+        if (g.cells[c].y > info->max_cell_entries) info->max_cell_entries = g.cells[c].y;
+        if (cell_begin) cell_begin[c] = g.cells[c].x;
+    }
+    if (cell_begin) cell_begin[g.cells.size()] = (uint32_t)g.entry_pos.size();
+    if (entry_sphere)
+        for (size_t e = 0; e < g.entry_pos.size(); ++e) entry_sphere[e] = nidx[g.entry_pos[e]];
+    if (loose_sphere)
+        for (size_t k = 0; k < g.loose.size(); ++k) loose_sphere[k] = nidx[g.loose[k]];
+    return DRAY_OK;
+}
+
 int scene_create_impl(const dray_sphere* sp, size_t n, int32_t device, dray_scene** out) {
     if (!out) return DRAY_ERR_INVALID_ARG;
     *out = nullptr;
@@ -335,14 +381,8 @@ int scene_create_impl(const dray_sphere* sp, size_t n, int32_t device, dray_scen
         g64[4 * k + 3] = r; m64[4 * k + 3] = f;
         g32[4 * k + 3] = (float)r; m32[4 * k + 3] = (float)f;
         kind[k] = sp[k].kind;
-        if (r >= kWideRadius) {
-            widx.push_back((int32_t)k);
-        } else {
-            nidx.push_back((int32_t)k);
-            ng.push_back((float)sp[k].center[0]); ng.push_back((float)sp[k].center[1]); ng.push_back((float)sp[k].center[2]);
-            ng.push_back((float)(r * r));
-        }
     }
+    classify_spheres(sp, n, ng, nidx, widx);
     d.n_narrow = (int32_t)nidx.size();
     d.n_wide = (int32_t)widx.size();
     while (nidx.size() % 8 != 0) { // padding entries can never be hit: their discriminant is -1e30 + h*h - |oc|^2 < 0
@@ -799,6 +839,15 @@ int dray_path_step_device(dray_scene* scene, int32_t image_width, dray_path_entr
                           const dray_opts* opts, void* stream) {
     try {
         return path_step_device_impl(scene, image_width, d_entries, n, opts, stream, false);
+    } catch (...) {
+        return DRAY_ERR_INTERNAL;
+    }
+}
+
+int dray_grid_inspect(const dray_sphere* spheres, size_t n_spheres, dray_grid_info* info, uint32_t* cell_begin,
+                      int32_t* entry_sphere, int32_t* loose_sphere) {
+    try {
+        return grid_inspect_impl(spheres, n_spheres, info, cell_begin, entry_sphere, loose_sphere);
     } catch (...) {
         return DRAY_ERR_INTERNAL;
     }

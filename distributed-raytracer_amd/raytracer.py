@@ -228,6 +228,21 @@ def write_ppm(path, color_buffer, width=None, height=None, binary=False):
     _ffi.check(_ffi.lib().dray_write_ppm(str(path).encode(), buf.ctypes.data, int(width), int(height), int(bool(binary))))
 
 
+def grid_inspect(world):
+    """The uniform grid the library builds for ``world`` (host only): (info, cell_begin, entry_sphere, loose_sphere)."""
+    spheres = flatten_world(world)
+    info = _ffi.GridInfo()
+    ptr = spheres.ctypes.data if len(spheres) else None
+    _ffi.check(_ffi.lib().dray_grid_inspect(ptr, len(spheres), C.byref(info), None, None, None))
+    n_cells = info.n[0] * info.n[1] * info.n[2]
+    cell_begin = np.zeros(n_cells + 1, dtype=np.uint32)
+    entry = np.zeros(max(int(info.n_entries), 1), dtype=np.int32)
+    loose = np.zeros(max(info.n_loose, 1), dtype=np.int32)
+    _ffi.check(_ffi.lib().dray_grid_inspect(ptr, len(spheres), C.byref(info), cell_begin.ctypes.data, entry.ctypes.data,
+                                            loose.ctypes.data))
+    return info, cell_begin, entry[:int(info.n_entries)], loose[:info.n_loose]
+
+
 # --------------------------------------------------------------- scene recipes --
 
 def scene_final(seed=1):

@@ -212,6 +212,23 @@ int dray_camera_rays_device(const dray_camera* cam, const dray_pixel_index* d_px
 int dray_path_step_device(dray_scene* scene, int32_t image_width, dray_path_entry* d_entries, size_t n,
                           const dray_opts* opts, void* stream);
 
+/* ---- the grid of the grid scan, as the host builds it (no GPU needed; for tools and tests) ---------------- */
+typedef struct dray_grid_info {
+    double lo[3], hi[3];       /* the grid's box */
+    int32_t n[3];              /* cells per axis (all 0: no sphere is walked) */
+    int32_t n_narrow, n_wide;  /* spheres scanned in f32 / intersected in f64 (radius >= 32) */
+    int32_t n_loose;           /* narrow spheres kept out of the grid (more than 512 cells, or not finite) */
+    uint64_t n_entries;        /* sphere listings over all cells */
+    uint32_t max_cell_entries;
+    uint32_t _pad;
+} dray_grid_info;
+/* Builds the uniform grid dray_scene_create builds for this list and reports it.  Call with the three arrays NULL
+ * to get the sizes, then with cell_begin[n[0]*n[1]*n[2] + 1] (cell (x, y, z) at (z*n[1] + y)*n[0] + x lists
+ * entry_sphere[cell_begin[c] .. cell_begin[c+1])), entry_sphere[n_entries] and loose_sphere[n_loose], which
+ * receive positions in the caller's list. */
+int dray_grid_inspect(const dray_sphere* spheres, size_t n_spheres, dray_grid_info* info, uint32_t* cell_begin,
+                      int32_t* entry_sphere, int32_t* loose_sphere);
+
 /* ---- scene recipes (host) ------------------------------------------------- */
 /* The scene built by the reference's local binary, main.rs:13-50, with its uniforms taken from the
  * Philox stream (pixel = sample = stage = 0xFFFFFFFF) of `seed`.  Returns the sphere count or a

@@ -191,3 +191,58 @@ def test_cpp_mirror_builds_and_fails_loudly_without_gpu(dray, tmp_path):
     p = subprocess.run([exe, "0", "21", "48", "4", "10", str(tmp_path / "x.ppm")], capture_output=True, text=True)
     assert p.returncode == 4 and "no HIP device" in p.stderr
     assert not (tmp_path / "x.ppm").exists()
+
+
+def _cell_of(info, p):
+    n = np.array(list(info.n))
+    lo, hi = np.array(list(info.lo)), np.array(list(info.hi))
+    c = np.floor((p - lo) / ((hi - lo) / n)).astype(np.int64)
+    return c
+
+
+def test_grid_lists_every_sphere_wherever_its_ball_reaches(dray):
+    """The grid scan may skip a sphere only in cells its ball does not reach.  For the reference scene, a 10 k-sphere
+    scene and a random cloud: every point of every listed sphere's ball (sampled on and inside the surface, and the
+    8 corners of its box shrunk onto the ball) lies in a cell that lists the sphere; loose and wide spheres are
+    exactly those the builder reports; every narrow sphere is listed or loose."""
+    rng = np.random.default_rng(11)
+    cloud = np.zeros(400, dtype=dray._ffi.SPHERE_DTYPE)
+    cloud["center"] = rng.uniform(-6, 6, size=(400, 3))
+    cloud["radius"] = rng.uniform(0.02, 1.2, size=400)
+    cloud["radius"][0] = 9.0     # spans too many cells: loose
+    cloud["radius"][1] = 500.0   # wide
+    cloud["center"][2] = (np.nan, 0, 0)  # not finite: loose
+    cloud["kind"] = 1
+    for spheres in (dray.scene_final(1), dray.scene_grid_10k(2)[::5], cloud):
+        info, cell_begin, entry, loose = dray.grid_inspect(spheres)
+        n = np.array(list(info.n))
+        assert (n >= 1).all() and (n <= 256).all()
+        assert info.n_narrow + info.n_wide == len(spheres)
+        wide = np.flatnonzero(np.maximum(spheres["radius"], 0) >= 32.0)
+        assert info.n_wide == len(wide)
+        listed = set(entry.tolist())
+        assert listed.isdisjoint(loose.tolist()) and listed.isdisjoint(wide.tolist())
+        assert len(listed) + len(loose) == info.n_narrow
+        assert int(np.diff(cell_begin.astype(np.int64)).max()) == info.max_cell_entries
+        cells = {}
+        for k in sorted(listed)[:: max(1, len(listed) // 150)]:
+            c, r = spheres["center"][k], max(float(spheres["radius"][k]), 0.0)
+            dirs = rng.normal(size=(40, 3))
+            dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+            corners = np.array([[sx, sy, sz] for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)]) / np.sqrt(3.0)
+            pts = np.concatenate([c + r * dirs, c + r * rng.uniform(0, 1, size=(40, 1)) * dirs, c + r * corners, c[None]])
+            for p in pts:
+                cx, cy, cz = _cell_of(info, p)
+                assert 0 <= cx < n[0] and 0 <= cy < n[1] and 0 <= cz < n[2], "the grid box holds every listed ball"
+                ci = (cz * n[1] + cy) * n[0] + cx
+                if ci not in cells:
+                    cells[ci] = set(entry[cell_begin[ci]:cell_begin[ci + 1]].tolist())
+                assert k in cells[ci], (k, p)
+        # a cell's entries are in insertion order
+        for ci in list(cells)[:50]:
+            e = entry[cell_begin[ci]:cell_begin[ci + 1]]
+            assert (np.diff(e) > 0).all()
+    info, cell_begin, entry, loose = dray.grid_inspect(cloud)
+    assert 0 in loose.tolist() and 2 in loose.tolist()
+    info, _, _, _ = dray.grid_inspect(np.zeros(0, dtype=dray._ffi.SPHERE_DTYPE))
+    assert list(info.n) == [0, 0, 0] and info.n_entries == 0
