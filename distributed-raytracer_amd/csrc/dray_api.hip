@@ -5,6 +5,7 @@
 // plain f64 expressions (src/raytracer/camera.rs:169-206).
 #pragma clang fp contract(off)
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -166,16 +167,36 @@ void build_grid(const std::vector<float>& ng, int32_t n_narrow, GridHost& g) {
     g = GridHost();
     if (n_narrow <= 0) return;
     std::vector<double> rad(n_narrow);
-    std::vector<char> odd(n_narrow, 0); // not finite: never hit by the exact test either; kept out of the grid
+    std::vector<char> odd(n_narrow, 0); // kept out of the grid: not finite (the exact test never accepts those), or outsized
     double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     int32_t n_regular = 0;
+    std::vector<double> finite_rad;
     for (int32_t p = 0; p < n_narrow; ++p) {
         rad[p] = std::sqrt((double)ng[4 * p + 3]) * (1.0 + 1e-6);
         if (!std::isfinite(rad[p]) || !std::isfinite(ng[4 * p]) || !std::isfinite(ng[4 * p + 1]) ||
-            !std::isfinite(ng[4 * p + 2])) {
+            !std::isfinite(ng[4 * p + 2]))
             odd[p] = 1;
-            continue;
-        }
+        else
+            finite_rad.push_back(rad[p]);
+    }
+    // A few spheres much larger than the rest would stretch the grid box over space the others leave empty and be
+    // listed in many cells: rays would step through all of it.  They are tested by every ray instead (a test costs
+    // less than one step), and the grid is laid over the others.
+    if (finite_rad.size() >= 16) {
+        double ratio = 3.0;
+        int max_big = 8;
+        if (const char* env = std::getenv("DRAY_GRID_BIG_RATIO")) ratio = std::atof(env);
+        if (const char* env = std::getenv("DRAY_GRID_BIG_MAX")) max_big = std::atoi(env);
+        std::nth_element(finite_rad.begin(), finite_rad.begin() + finite_rad.size() / 2, finite_rad.end());
+        const double limit = ratio * finite_rad[finite_rad.size() / 2];
+        int n_big = 0;
+        for (int32_t p = 0; p < n_narrow; ++p) n_big += (!odd[p] && rad[p] > limit) ? 1 : 0;
+        if (ratio > 0. && n_big <= max_big)
+            for (int32_t p = 0; p < n_narrow; ++p)
+                if (!odd[p] && rad[p] > limit) odd[p] = 1;
+    }
+    for (int32_t p = 0; p < n_narrow; ++p) {
+        if (odd[p]) continue;
         ++n_regular;
         for (int a = 0; a < 3; ++a) {
             lo[a] = std::fmin(lo[a], (double)ng[4 * p + a] - rad[p]);
