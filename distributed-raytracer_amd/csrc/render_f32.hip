@@ -867,9 +867,16 @@ F32Plan plan_render_f32(const CamDev<float>& cam, const Partition& part, int32_t
     // (a long brute-force scan per segment) need small grabs to keep the last waves' tail short.  Measured: 3-sphere
     // full-HD frame 13.2 / 9.6 / 9.3 ms at 256 / 512 / 1024 samples per grab, 485-sphere hybrid scan 21.0 / 22.1 /
     // 25.4 ms, grid scan 9.7 / 9.5 / 9.8 ms (100 spp).
-    const int32_t tests_per_segment = plan.scan == DRAY_SCAN_GRID ? 32 : scene.n_narrow_padded;
+    // With the grid scan (a segment costs about as much as 8 tests plus the 16 of shading): 1200x675 frame of 125 /
+    // 250 / 500 spp 7.80 / 14.86 / 27.21 ms at 341 samples per grab, 7.36 / 14.03 / 27.24 ms at 700; one rank's
+    // eighth of it 1.49 / 2.31 / 3.91 against 1.89 / 2.40 / 3.97 ms -- a small launch needs small grabs, so the first
+    // round of grabs may take a sixteenth of the launch at most.
+    const int32_t tests_per_segment = plan.scan == DRAY_SCAN_GRID ? 8 : scene.n_narrow_padded;
     int32_t grab_samples = kGrabWork / (tests_per_segment + 16);
     grab_samples = grab_samples < 128 ? 128 : (grab_samples > 1024 ? 1024 : grab_samples);
+    const long long sixteenth = (long long)(part.n_rows > 0 ? part.n_rows : 0) * cam.W * (cam.spp > 0 ? cam.spp : 1) /
+                             (16LL * plan.grid * (plan.block / 64));
+    if (sixteenth < grab_samples) grab_samples = sixteenth < 128 ? 128 : (int32_t)sixteenth;
     if (const char* env = std::getenv("DRAY_GRAB_SAMPLES")) { // tuning runs only
         const int v = std::atoi(env);
         if (v > 0) grab_samples = v;

@@ -1,7 +1,5 @@
 set -e
 cd $GRAFT_REPO_ROOT
-timeout -k 10 600 python -u -m pytest tests -m gpu -x -q --timeout 120 --timeout-method thread 2>&1 | tail -3
-for sc in "grid10k --spp 20" "glass_metal --spp 200 --depth 100" "final --spp 100" "final --spp 10"; do
-DRAY_GRID_BIG_RATIO=0 timeout -k 10 120 python tools/ab_bench.py --variants 3 --rounds 5 --scene $sc --tag "old $sc"
-timeout -k 10 120 python tools/ab_bench.py --variants 3 --rounds 5 --scene $sc --tag "new $sc"
-done
+for l in base items items_f4 items_f8 items_f16; do echo "lib $l"; DRAY_HIP_LIB=tools/ab_libs/$l.so timeout -k 10 200 python tools/fixed_cost.py --spp 250 500 1000; done
+echo "lib items_f8 grab 1024";  DRAY_GRAB_SAMPLES=1024 DRAY_HIP_LIB=tools/ab_libs/items_f8.so timeout -k 10 200 python tools/fixed_cost.py --spp 250 500 1000
+echo "lib items_f16 grab 1024";  DRAY_GRAB_SAMPLES=1024 DRAY_HIP_LIB=tools/ab_libs/items_f16.so timeout -k 10 200 python tools/fixed_cost.py --spp 250 500 1000

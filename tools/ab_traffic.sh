@@ -18,9 +18,12 @@ res = {}
 for f in sorted(glob.glob(sys.argv[1] + "/*counter_collection.csv")):
     for r in csv.DictReader(open(f)):
         name = r["Kernel_Name"]
-        short = "render_f32_kernel" if "render_f32" in name else "resolve_f32_kernel" if "resolve" in name else None
+        # bench.py times the default (grid, <3>) kernel and then the brute-force (hybrid, <2>) one: keep them apart,
+        # and take each kernel's first dispatch
+        short = ("render_f32_kernel<3>" if "render_f32_kernel<3>" in name else "render_f32_kernel<2>" if "render_f32_kernel<2>" in name
+                 else "render_f32_kernel<1>" if "render_f32" in name else "resolve_f32_kernel" if "resolve" in name else None)
         if short:
-            res.setdefault(short, {})[r["Counter_Name"] + "_KiB"] = float(r["Counter_Value"])
+            res.setdefault(short, {}).setdefault(r["Counter_Name"] + "_KiB", float(r["Counter_Value"]))
 for k, v in res.items():
     # FETCH_SIZE counts a wide coalesced read at half its bytes on gfx950: doubled here; WRITE_SIZE is taken as is
     v["bytes_per_launch"] = 2 * 1024 * v.get("FETCH_SIZE_KiB", 0.0) + 1024 * v.get("WRITE_SIZE_KiB", 0.0)
