@@ -1,5 +1,6 @@
 set -e
 cd $GRAFT_REPO_ROOT
-for l in base items items_f4 items_f8 items_f16; do echo "lib $l"; DRAY_HIP_LIB=tools/ab_libs/$l.so timeout -k 10 200 python tools/fixed_cost.py --spp 250 500 1000; done
-echo "lib items_f8 grab 1024";  DRAY_GRAB_SAMPLES=1024 DRAY_HIP_LIB=tools/ab_libs/items_f8.so timeout -k 10 200 python tools/fixed_cost.py --spp 250 500 1000
-echo "lib items_f16 grab 1024";  DRAY_GRAB_SAMPLES=1024 DRAY_HIP_LIB=tools/ab_libs/items_f16.so timeout -k 10 200 python tools/fixed_cost.py --spp 250 500 1000
+timeout -k 10 200 python tools/ab_bench.py --variants 3 --rounds 3 --scene grid10k --width 3840 --spp 256 --tag config4
+timeout -k 10 200 python tools/ab_bench.py --variants 3 --rounds 3 --scene glass_metal --spp 1000 --depth 100 --tag config5
+timeout -k 10 200 python tools/ab_bench.py --variants 1 --rounds 3 --scene three --width 1920 --spp 100 --tag config2
+timeout -k 10 200 python tools/ab_bench.py --variants 1 --rounds 3 --scene three --width 400 --spp 10 --depth 10 --tag config1
