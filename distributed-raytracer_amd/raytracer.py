@@ -142,6 +142,9 @@ class Camera:
         self.flags = 0
         self.sample_offset = 0
         self.device = -1
+        # > 0: render in passes of this many samples per pixel and refresh the window after each pass (the reference
+        # refreshes it after every pixel sample, colors.rs:44); the buffers end up the same as after one pass
+        self.samples_per_pass = 0
         self.last_stats = None
 
     @classmethod
@@ -183,8 +186,8 @@ class Camera:
 
         color_buffer: uint32[>= W*H]; raw_buffer: float64[>= W*H, 3] or None; count_buffer: int32[>= W*H] or None.
         The buffers are accumulated into, never cleared (colors.rs:38-39).  ``window`` (may be None) gets one
-        ``update_with_buffer(color_buffer, W, H)`` per call instead of one per pixel sample (colors.rs:44).
-        Raises DrayError where the Rust binding would return an io::Error.
+        ``update_with_buffer(color_buffer, W, H)`` per pass (one pass unless ``samples_per_pass`` is set) instead
+        of one per pixel sample (colors.rs:44).  Raises DrayError where the Rust binding would return an io::Error.
         """
         spheres = flatten_world(world)
         self.initialize()
@@ -203,15 +206,34 @@ class Camera:
             buf_len = count_buffer.size
         pod = self.pod()
         opts = self.opts(**opt_overrides)
-        st = _ffi.Stats()
-        rc = _ffi.lib().dray_render(
-            C.byref(pod), spheres.ctypes.data if len(spheres) else None, len(spheres), color_buffer.ctypes.data,
-            raw_buffer.ctypes.data if raw_buffer is not None else None,
-            count_buffer.ctypes.data if count_buffer is not None else None, buf_len, C.byref(opts), C.byref(st))
-        _ffi.check(rc)
-        self.last_stats = st
-        if window is not None:
-            window.update_with_buffer(color_buffer, self.image_width, self.image_height)
+        total = int(self.samples_per_pixel)
+        per_pass = int(self.samples_per_pass) if 0 < int(self.samples_per_pass) < total else total
+        first_sample = opts.sample_offset
+        done = 0
+        whole = None
+        while True:  # at least one call, so that a camera of 0 samples fails (or not) the way one call does
+            pod.samples_per_pixel = min(per_pass, total - done) if total > 0 else total
+            opts.sample_offset = first_sample + done
+            st = _ffi.Stats()
+            rc = _ffi.lib().dray_render(
+                C.byref(pod), spheres.ctypes.data if len(spheres) else None, len(spheres), color_buffer.ctypes.data,
+                raw_buffer.ctypes.data if raw_buffer is not None else None,
+                count_buffer.ctypes.data if count_buffer is not None else None, buf_len, C.byref(opts), C.byref(st))
+            _ffi.check(rc)
+            if whole is None:
+                whole = st
+            else:  # the call's totals over its passes
+                for f in ("segments", "samples", "walk_steps"):
+                    setattr(whole, f, getattr(whole, f) + getattr(st, f))
+                for f in ("kernel_ms", "resolve_ms", "total_ms"):
+                    if hasattr(whole, f):
+                        setattr(whole, f, getattr(whole, f) + getattr(st, f))
+            if window is not None:
+                window.update_with_buffer(color_buffer, self.image_width, self.image_height)
+            done += pod.samples_per_pixel
+            if done >= total:
+                break
+        self.last_stats = whole
         return None  # Ok(())
 
 

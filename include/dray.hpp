@@ -152,7 +152,10 @@ class Camera {
 
     // backend options, not in the reference: see dray_opts
     dray_opts opts;
-    dray_stats last_stats{};
+    // > 0: render in passes of this many samples per pixel and call `present` after each pass; the buffers end up
+    // the same as after one pass of samples_per_pixel
+    int32_t samples_per_pass = 0;
+    dray_stats last_stats{}; // of the whole call (counts and times summed over its passes)
 
     Camera() { dray_opts_default(&opts); }
     static Camera create() { return Camera(); } // Camera::new
@@ -183,22 +186,40 @@ class Camera {
 
     // Camera::render.  The buffers hold at least image_width * image_height pixels (the reference's caller sizes
     // them image_width^2, main.rs:69-73) and are added to, never cleared (colors.rs:38-39).  `present`, if
-    // given, is called once with the finished colour buffer where the reference refreshes its window after
-    // every sample (colors.rs:44).
+    // given, is called with the colour buffer after every pass (one pass unless samples_per_pass is set) where
+    // the reference refreshes its window after every pixel sample (colors.rs:44).
     template <typename Present>
     void render(const Hittable& world, Present&& present, std::vector<uint32_t>& color_buffer,
                 std::vector<double>& raw_buffer, std::vector<int32_t>& count_buffer) {
         std::vector<dray_sphere> spheres;
         world.flatten(spheres);
-        const dray_camera c = pod();
+        dray_camera c = pod();
         size_t buf_len = color_buffer.size();
         if (!raw_buffer.empty() && raw_buffer.size() / 3 < buf_len) buf_len = raw_buffer.size() / 3;
         if (!count_buffer.empty() && count_buffer.size() < buf_len) buf_len = count_buffer.size();
-        check(dray_render(&c, spheres.empty() ? nullptr : spheres.data(), spheres.size(), color_buffer.data(),
-                          raw_buffer.empty() ? nullptr : raw_buffer.data(),
-                          count_buffer.empty() ? nullptr : count_buffer.data(), buf_len, &opts, &last_stats),
-              "Camera::render");
-        present(color_buffer, image_width, last_stats.image_height);
+        const int32_t total = samples_per_pixel;
+        const int32_t per_pass = samples_per_pass > 0 && samples_per_pass < total ? samples_per_pass : total;
+        dray_opts o = opts;
+        dray_stats whole{};
+        int32_t done = 0;
+        do { // at least one call, so that a camera of 0 samples fails (or not) the way one call does
+            c.samples_per_pixel = total > 0 && total - done < per_pass ? total - done : per_pass;
+            o.sample_offset = opts.sample_offset + (uint32_t)done;
+            dray_stats st{};
+            check(dray_render(&c, spheres.empty() ? nullptr : spheres.data(), spheres.size(), color_buffer.data(),
+                              raw_buffer.empty() ? nullptr : raw_buffer.data(),
+                              count_buffer.empty() ? nullptr : count_buffer.data(), buf_len, &o, &st),
+                  "Camera::render");
+            if (done == 0) {
+                whole = st;
+            } else {
+                whole.segments += st.segments; whole.samples += st.samples; whole.walk_steps += st.walk_steps;
+                whole.kernel_ms += st.kernel_ms; whole.resolve_ms += st.resolve_ms; whole.total_ms += st.total_ms;
+            }
+            present(color_buffer, image_width, st.image_height);
+            done += c.samples_per_pixel;
+        } while (done < total);
+        last_stats = whole;
     }
     void render(const Hittable& world, std::vector<uint32_t>& color_buffer, std::vector<double>& raw_buffer,
                 std::vector<int32_t>& count_buffer) {

@@ -49,6 +49,19 @@ int main(int argc, char** argv) {
             if (!f || std::fwrite(raw.data(), sizeof(double), (size_t)W * H * 3, f) != (size_t)W * H * 3) return 74;
             std::fclose(f);
         }
+        // the same frame again in passes of 3 samples: one present per pass, the same buffers, the same totals
+        if (cam.samples_per_pixel > 3) {
+            std::vector<uint32_t> color3((size_t)W * W, 0u);
+            std::vector<double> raw3((size_t)W * W * 3, 0.0);
+            std::vector<int32_t> count3((size_t)W * W, 0);
+            presents = 0;
+            cam.samples_per_pass = 3;
+            cam.render(world, [&](const std::vector<uint32_t>&, int32_t, int32_t) { ++presents; }, color3, raw3, count3);
+            cam.samples_per_pass = 0;
+            if (presents != (cam.samples_per_pixel + 2) / 3) return 75;
+            if (color3 != color || raw3 != raw || count3 != count) return 76;
+            if (cam.last_stats.segments != first.segments || cam.last_stats.samples != first.samples) return 77;
+        }
         // the same frame again through the resumable path state: rays for every (pixel, sample), stepped until all
         // are finished, colours summed per pixel in sample order (left-to-right product, camera.rs:118-144)
         unsigned long long step_segments = 0;

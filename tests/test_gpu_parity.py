@@ -535,6 +535,39 @@ def test_cpp_mirror_matches_python_binding(dray, gpu, oracle, tmp_path):
     assert (oraw == raw[:W * H].reshape(H, W, 3)).all() and ost.segments == info["segments"]
 
 
+def test_progressive_passes_equal_one_pass(dray, gpu):
+    """Camera.render in passes (samples_per_pass): the window is refreshed after every pass, where the reference
+    refreshes it after every pixel sample (colors.rs:44), and colour, sums, counts and totals equal one pass of all
+    the samples -- in the f64 mode and in the f32 mode."""
+    class Window:
+        def __init__(self):
+            self.frames = []
+
+        def update_with_buffer(self, buf, w, h):
+            self.frames.append((buf[:w * h].copy(), w, h))
+
+    world = dray.scene_three_spheres()
+    for mode in (dray.MODE_F64, dray.MODE_F32):
+        results = []
+        for per_pass in (0, 4, 7, 100):
+            cam = dray.camera_three_spheres(width=64, spp=10, depth=10)
+            cam.mode, cam.seed, cam.samples_per_pass = mode, 5, per_pass
+            W = 64
+            color, raw, count = np.zeros(W * W, np.uint32), np.zeros((W * W, 3), np.float64), np.zeros(W * W, np.int32)
+            win = Window()
+            cam.render(world, win, color, raw, count)
+            passes = 1 if per_pass in (0, 100) else -(-10 // per_pass)
+            assert len(win.frames) == passes and win.frames[-1][1:] == (W, cam.image_height)
+            assert (win.frames[-1][0] == color[:W * cam.image_height]).all()
+            if passes > 1:  # earlier frames show the image so far: already drawn, not yet final
+                assert win.frames[0][0].any() and (win.frames[0][0] != win.frames[-1][0]).any()
+            assert cam.last_stats.samples == 10 * W * cam.image_height
+            results.append((color, raw, count, cam.last_stats.segments))
+        for r in results[1:]:
+            assert (r[0] == results[0][0]).all() and (r[1] == results[0][1]).all() and (r[2] == results[0][2]).all()
+            assert r[3] == results[0][3]
+
+
 def test_path_step_matches_oracle(dray, gpu, oracle):
     """dray_camera_rays / dray_path_step (CameraRayIterator::next, ray_color_iteration; camera.rs:103-144): every
     field of every entry equals the oracle's after every step, for a shuffled pixel order (camera.rs:96-98), and the
