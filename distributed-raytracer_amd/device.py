@@ -115,6 +115,20 @@ def camera_rays(cam: Camera, pixel_indices, **opt_overrides):
     return out
 
 
+def iterate_rays(cam: Camera, shuffle_seed=0, **opt_overrides):
+    """Camera::iterate_rays (camera.rs:165, CameraRayIterator :68-116): every pixel of the image once, with sample
+    number 0 (the iterator stops after image_width * image_height items, :93-95), in a shuffled order (:96-98;
+    the reference shuffles with an OS-seeded generator, here the order is numpy's permutation for ``shuffle_seed``).
+    Returns (pixel_indices int32[n, 3], entries): the i-th item of the reference's iterator is
+    (PixelIndexEntry(*pixel_indices[i]), entries[i]'s origin and direction), already wrapped as
+    RayColorEntry::new(ray, max_depth) the way its consumer does (ray_server.rs:48-51)."""
+    cam.initialize()
+    W, H = int(cam.image_width), int(cam.image_height)
+    order = np.random.default_rng(shuffle_seed).permutation(W * H)
+    px = np.stack([order % W, order // W, np.zeros_like(order)], axis=1).astype(np.int32)  # camera.rs:103-106
+    return px, camera_rays(cam, px, **opt_overrides)
+
+
 def ray_color_iteration(entries, scene: DeviceScene, cam: Camera, **opt_overrides):
     """One ray_color_iteration (camera.rs:118-144) on every unfinished entry of the batch, in place; returns the
     call's statistics (segments = entries that were intersected)."""

@@ -12,8 +12,10 @@
 // Only render does work: it flattens the world and calls dray_render.
 #pragma once
 
+#include <algorithm>
 #include <cstdint>
 #include <memory>
+#include <random>
 #include <stdexcept>
 #include <string>
 #include <utility>
@@ -256,6 +258,23 @@ inline std::vector<RayColorEntry> camera_rays(const Camera& cam, const std::vect
     const dray_camera c = cam.pod();
     check(dray_camera_rays(&c, px.data(), px.size(), out.data(), &cam.opts), "camera_rays");
     return out;
+}
+
+// Camera::iterate_rays (camera.rs:165, CameraRayIterator :68-116): every pixel of the image once, sample number 0
+// (the iterator stops after image_width * image_height items, :93-95), in a shuffled order (:96-98; the reference
+// shuffles with an OS-seeded generator, here with std::mt19937_64 seeded by `shuffle_seed`).  Item k of the
+// reference's iterator is (first[k], the ray of second[k]); second[k] is already RayColorEntry::new(ray, max_depth).
+inline std::pair<std::vector<PixelIndexEntry>, std::vector<RayColorEntry>> iterate_rays(const Camera& cam,
+                                                                                        uint64_t shuffle_seed = 0) {
+    const int32_t W = cam.image_width, H = cam.image_height();
+    std::vector<int32_t> seq((size_t)W * (size_t)H);
+    for (size_t k = 0; k < seq.size(); ++k) seq[k] = (int32_t)k;
+    std::mt19937_64 gen(shuffle_seed);
+    std::shuffle(seq.begin(), seq.end(), gen);
+    std::vector<PixelIndexEntry> px(seq.size());
+    for (size_t k = 0; k < seq.size(); ++k) px[k] = PixelIndexEntry{seq[k] % W, seq[k] / W, 0}; // camera.rs:103-106
+    std::vector<RayColorEntry> entries = camera_rays(cam, px);
+    return {std::move(px), std::move(entries)};
 }
 
 // ray_color_iteration (camera.rs:118-144) on every unfinished entry, in place.  Returns the number intersected.

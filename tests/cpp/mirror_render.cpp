@@ -8,6 +8,7 @@
 // Exit code: 0, or the negated dray_status of the failing call (4 = no GPU).
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <string>
 
 #include "dray.hpp"
@@ -78,6 +79,22 @@ int main(int argc, char** argv) {
                     for (int32_t i = 0; i < W; ++i) px.push_back(PixelIndexEntry{i, j, s});
             DeviceScene scene(world);
             std::vector<RayColorEntry> entries = camera_rays(cam, px);
+            // Camera::iterate_rays: every pixel once, sample 0, shuffled; each item equals the entry asked for in order
+            {
+                const auto it = iterate_rays(cam, 7);
+                if (it.first.size() != (size_t)W * H || it.second.size() != it.first.size()) return 78;
+                std::vector<char> seen((size_t)W * H, 0);
+                bool identity = true;
+                for (size_t k = 0; k < it.first.size(); ++k) {
+                    const PixelIndexEntry& q = it.first[k];
+                    if (q.pixel_sample_num != 0 || q.pixel_i < 0 || q.pixel_i >= W || q.pixel_j < 0 || q.pixel_j >= H) return 78;
+                    const size_t at = (size_t)q.pixel_j * W + q.pixel_i; // = its place in the ordered first pass of px
+                    if (seen[at]++) return 78;
+                    identity = identity && at == k;
+                    if (std::memcmp(&it.second[k], &entries[at], sizeof(RayColorEntry)) != 0) return 79;
+                }
+                if (identity) return 78;
+            }
             for (int guard = 0; guard <= cam.max_depth + 1; ++guard) {
                 const uint64_t moved = ray_color_iteration(entries, scene, cam);
                 step_segments += moved;

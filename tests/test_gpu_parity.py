@@ -568,6 +568,21 @@ def test_progressive_passes_equal_one_pass(dray, gpu):
             assert r[3] == results[0][3]
 
 
+def test_iterate_rays_is_one_shuffled_pass(dray, gpu, oracle):
+    """Camera::iterate_rays (camera.rs:68-116, :165): image_width * image_height items, every pixel once, sample
+    number 0, not in scan order; each item is the oracle's camera ray for that pixel."""
+    cam = dray.camera_final(width=48, spp=3, depth=7)
+    cam.mode, cam.seed = dray.MODE_F64, 4
+    px, e = gpu.iterate_rays(cam, shuffle_seed=2)
+    H, W = cam.image_height, cam.image_width
+    assert px.shape == (W * H, 3) and len(e) == W * H
+    flat = px[:, 1].astype(np.int64) * W + px[:, 0]
+    assert (np.sort(flat) == np.arange(W * H)).all() and (px[:, 2] == 0).all() and (flat != np.arange(W * H)).any()
+    assert (gpu.iterate_rays(cam, shuffle_seed=2)[0] == px).all() and (gpu.iterate_rays(cam, shuffle_seed=3)[0] != px).any()
+    assert e.tobytes() == oracle.camera_ray_entries(ocam_from(oracle, cam), px, seed=4).tobytes()
+    assert (e["depth"] == 7).all() and (e["attenuation"] == 1.0).all() and (e["finished"] == 0).all()
+
+
 def test_path_step_matches_oracle(dray, gpu, oracle):
     """dray_camera_rays / dray_path_step (CameraRayIterator::next, ray_color_iteration; camera.rs:103-144): every
     field of every entry equals the oracle's after every step, for a shuffled pixel order (camera.rs:96-98), and the
