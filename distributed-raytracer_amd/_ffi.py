@@ -127,7 +127,7 @@ class GridInfo(C.Structure):
 
 EXPORTS = (
     "dray_version", "dray_strerror", "dray_device_count", "dray_opts_default", "dray_camera_default",
-    "dray_camera_initialize", "dray_render", "dray_scene_create", "dray_scene_destroy", "dray_render_device",
+    "dray_camera_initialize", "dray_render", "dray_render_multi", "dray_scene_create", "dray_scene_destroy", "dray_render_device",
     "dray_scene_final", "dray_scene_recipe", "dray_scene_three_spheres", "dray_write_ppm", "dray_camera_rays",
     "dray_path_step", "dray_camera_rays_device", "dray_path_step_device", "dray_grid_inspect",
 )
@@ -171,6 +171,8 @@ def lib():
     L.dray_camera_initialize.argtypes = [P(CameraPOD), P(CameraDerivedPOD)]
     L.dray_render.argtypes = [P(CameraPOD), C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                               P(Opts), P(Stats)]
+    L.dray_render_multi.argtypes = [P(CameraPOD), C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                    P(Opts), C.c_void_p, C.c_int32, P(Stats)]
     L.dray_scene_create.argtypes = [C.c_void_p, C.c_size_t, C.c_int32, P(C.c_void_p)]
     L.dray_scene_destroy.restype = None
     L.dray_scene_destroy.argtypes = [C.c_void_p]

@@ -12,6 +12,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "dray_internal.h"
@@ -619,6 +621,126 @@ int render_host_impl(const dray_camera* cam, const dray_sphere* spheres, size_t 
     return rc;
 }
 
+// One device's share of a frame rendered for host buffers: scanlines `share`, `share + n_shares`, ... on `device`,
+// uploaded from and written back to those rows of the caller's buffers (strided copies).
+int render_share(const dray_camera* cam, const dray_sphere* spheres, size_t n, uint32_t* color, double* raw, int32_t* count,
+                 const dray_opts& base, int32_t device, int32_t share, int32_t n_shares, size_t W, size_t H,
+                 dray_stats* stats) {
+    const size_t n_rows = (size_t)share < H ? (H - share + n_shares - 1) / n_shares : 0;
+    std::memset(stats, 0, sizeof *stats);
+    if (n_rows == 0) return DRAY_OK;
+    dray_scene* scene = nullptr;
+    int rc = scene_create_impl(spheres, n, device, &scene);
+    if (rc) return rc;
+    DeviceGuard g(scene->device);
+    uint32_t* d_color = nullptr;
+    double* d_raw = nullptr;
+    int32_t* d_count = nullptr;
+    auto cleanup = [&]() {
+        (void)hipFree(d_color); (void)hipFree(d_raw); (void)hipFree(d_count);
+        scene_free(scene);
+    };
+    auto fail = [&](hipError_t e, const char* what) { int r = hip_fail(e, what); cleanup(); return r; };
+    const size_t slab = n_rows * W;
+    // image row share + k * n_shares <-> slab row k
+    auto rows = [&](void* dev, void* host, size_t elem, hipMemcpyKind kind) {
+        char* h = (char*)host + (size_t)share * W * elem;
+        const size_t host_pitch = (size_t)n_shares * W * elem, dev_pitch = W * elem;
+        return kind == hipMemcpyHostToDevice ? hipMemcpy2D(dev, dev_pitch, h, host_pitch, W * elem, n_rows, kind)
+                                             : hipMemcpy2D(h, host_pitch, dev, dev_pitch, W * elem, n_rows, kind);
+    };
+    hipError_t e;
+    if ((e = hipMalloc((void**)&d_color, slab * sizeof(uint32_t))) != hipSuccess) return fail(e, "hipMalloc color");
+    if (raw) {
+        if ((e = hipMalloc((void**)&d_raw, slab * 3 * sizeof(double))) != hipSuccess) return fail(e, "hipMalloc raw");
+        if ((e = rows(d_raw, raw, 3 * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "upload raw");
+    }
+    if (count) {
+        if ((e = hipMalloc((void**)&d_count, slab * sizeof(int32_t))) != hipSuccess) return fail(e, "hipMalloc count");
+        if ((e = rows(d_count, count, sizeof(int32_t), hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "upload count");
+    }
+    dray_opts opts = base;
+    opts.device = scene->device;
+    opts.row_begin = share;
+    opts.row_step = n_shares;
+    opts.flags |= DRAY_FLAG_COMPACT_ROWS;
+    rc = render_device_impl(cam, scene, d_color, d_raw, d_count, slab, &opts, nullptr, stats);
+    if (rc == DRAY_OK) {
+        if ((e = hipDeviceSynchronize()) != hipSuccess) return fail(e, "hipDeviceSynchronize");
+        if ((e = rows(d_color, color, sizeof(uint32_t), hipMemcpyDeviceToHost)) != hipSuccess) return fail(e, "download color");
+        if (raw && (e = rows(d_raw, raw, 3 * sizeof(double), hipMemcpyDeviceToHost)) != hipSuccess) return fail(e, "download raw");
+        if (count && (e = rows(d_count, count, sizeof(int32_t), hipMemcpyDeviceToHost)) != hipSuccess) return fail(e, "download count");
+    }
+    cleanup();
+    return rc;
+}
+
+// Camera::render over several GPUs from one process: one host thread per share.
+int render_multi_impl(const dray_camera* cam, const dray_sphere* spheres, size_t n, uint32_t* color, double* raw,
+                      int32_t* count, size_t buf_len, const dray_opts* opts_in, const int32_t* devices, int32_t n_devices,
+                      dray_stats* stats) {
+    const auto t_begin = std::chrono::steady_clock::now();
+    if (!camera_ok(cam) || !color || (!spheres && n)) return DRAY_ERR_INVALID_ARG;
+    dray_opts opts;
+    if (opts_in) opts = *opts_in; else dray_opts_default(&opts);
+    // the row partition is this call's to make
+    if (opts.row_begin != 0 || opts.row_step > 1 || (opts.flags & DRAY_FLAG_COMPACT_ROWS)) return DRAY_ERR_INVALID_ARG;
+    int visible = 0;
+    if (hipGetDeviceCount(&visible) != hipSuccess || visible < 1) return DRAY_ERR_NO_DEVICE;
+    std::vector<int32_t> devs;
+    if (n_devices <= 0) n_devices = visible;              // every visible GPU
+    if (n_devices > 64) return DRAY_ERR_INVALID_ARG;
+    for (int32_t k = 0; k < n_devices; ++k) {
+        const int32_t d = devices ? devices[k] : k;
+        if (d < 0 || d >= visible) return DRAY_ERR_INVALID_ARG;
+        devs.push_back(d);
+    }
+    for (size_t k = 0; k < n; ++k)
+        if (spheres[k].kind > DRAY_MAT_DIELECTRIC) return DRAY_ERR_UNSUPPORTED;
+    dray_camera_derived dv;
+    int rc = dray_camera_initialize(cam, &dv);
+    if (rc) return rc;
+    const size_t W = (size_t)cam->image_width, H = (size_t)dv.image_height;
+    if (buf_len < W * H) return DRAY_ERR_BUFFER_TOO_SMALL;
+    const bool exact_product = opts.mode != DRAY_MODE_F32 && !(opts.flags & DRAY_FLAG_ITERATIVE_PRODUCT);
+    if (opts.mode > DRAY_MODE_F32_PLAIN || opts.variant < 0 || opts.variant > DRAY_SCAN_GRID) return DRAY_ERR_INVALID_ARG;
+    if (exact_product && cam->max_depth > kExactMaxDepth) return DRAY_ERR_UNSUPPORTED;
+    if (stats) {
+        std::memset(stats, 0, sizeof *stats);
+        stats->image_height = (int32_t)H;
+        stats->n_spheres = (int32_t)n;
+    }
+    if (cam->samples_per_pixel <= 0) return DRAY_OK; // camera.rs:217: no samples, no writes
+
+    const int32_t G = (int32_t)devs.size();
+    std::vector<dray_stats> st((size_t)G);
+    std::vector<int> rcs((size_t)G, DRAY_OK);
+    std::vector<std::string> detail((size_t)G);
+    std::vector<std::thread> workers;
+    for (int32_t g = 0; g < G; ++g)
+        workers.emplace_back([&, g]() {
+            rcs[g] = render_share(cam, spheres, n, color, raw, count, opts, devs[g], g, G, W, H, &st[g]);
+            if (rcs[g]) detail[g] = g_detail; // the failure text lives in the worker's thread
+        });
+    for (auto& w : workers) w.join();
+    for (int32_t g = 0; g < G; ++g)
+        if (rcs[g]) {
+            snprintf(g_detail, sizeof g_detail, "device %d: %s", devs[g], detail[g].c_str());
+            return rcs[g];
+        }
+    if (stats) {
+        for (const dray_stats& s : st) {
+            stats->segments += s.segments; stats->samples += s.samples; stats->walk_steps += s.walk_steps;
+            stats->rows_rendered += s.rows_rendered;
+            stats->kernel_ms = std::fmax(stats->kernel_ms, s.kernel_ms);   // the shares run side by side
+            stats->resolve_ms = std::fmax(stats->resolve_ms, s.resolve_ms);
+            if (s.n_wide_spheres > stats->n_wide_spheres) stats->n_wide_spheres = s.n_wide_spheres;
+        }
+        stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    }
+    return DRAY_OK;
+}
+
 int resolve_device(const dray_opts& opts, int* device) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return DRAY_ERR_NO_DEVICE;
@@ -800,6 +922,16 @@ int dray_render(const dray_camera* cam, const dray_sphere* spheres, size_t n_sph
                 int32_t* count, size_t buf_len, const dray_opts* opts, dray_stats* stats) {
     try {
         return render_host_impl(cam, spheres, n_spheres, color, raw, count, buf_len, opts, stats);
+    } catch (...) {
+        return DRAY_ERR_INTERNAL;
+    }
+}
+
+int dray_render_multi(const dray_camera* cam, const dray_sphere* spheres, size_t n_spheres, uint32_t* color, double* raw,
+                      int32_t* count, size_t buf_len, const dray_opts* opts, const int32_t* devices, int32_t n_devices,
+                      dray_stats* stats) {
+    try {
+        return render_multi_impl(cam, spheres, n_spheres, color, raw, count, buf_len, opts, devices, n_devices, stats);
     } catch (...) {
         return DRAY_ERR_INTERNAL;
     }

@@ -145,6 +145,9 @@ class Camera:
         # > 0: render in passes of this many samples per pixel and refresh the window after each pass (the reference
         # refreshes it after every pixel sample, colors.rs:44); the buffers end up the same as after one pass
         self.samples_per_pass = 0
+        # GPUs of this node to spread a render over from this one process: None = the one device above; a list of
+        # device numbers (a device may appear more than once); "all" = every visible GPU
+        self.devices = None
         self.last_stats = None
 
     @classmethod
@@ -215,10 +218,16 @@ class Camera:
             pod.samples_per_pixel = min(per_pass, total - done) if total > 0 else total
             opts.sample_offset = first_sample + done
             st = _ffi.Stats()
-            rc = _ffi.lib().dray_render(
-                C.byref(pod), spheres.ctypes.data if len(spheres) else None, len(spheres), color_buffer.ctypes.data,
-                raw_buffer.ctypes.data if raw_buffer is not None else None,
-                count_buffer.ctypes.data if count_buffer is not None else None, buf_len, C.byref(opts), C.byref(st))
+            args = (C.byref(pod), spheres.ctypes.data if len(spheres) else None, len(spheres), color_buffer.ctypes.data,
+                    raw_buffer.ctypes.data if raw_buffer is not None else None,
+                    count_buffer.ctypes.data if count_buffer is not None else None, buf_len, C.byref(opts))
+            if self.devices is None:
+                rc = _ffi.lib().dray_render(*args, C.byref(st))
+            elif isinstance(self.devices, str):  # "all"
+                rc = _ffi.lib().dray_render_multi(*args, None, 0, C.byref(st))
+            else:
+                devs = np.ascontiguousarray(self.devices, dtype=np.int32)
+                rc = _ffi.lib().dray_render_multi(*args, devs.ctypes.data, len(devs), C.byref(st))
             _ffi.check(rc)
             if whole is None:
                 whole = st

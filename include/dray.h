@@ -166,6 +166,17 @@ int dray_camera_initialize(const dray_camera* cam, dray_camera_derived* out);
 int dray_render(const dray_camera* cam, const dray_sphere* spheres, size_t n_spheres, uint32_t* color, double* raw,
                 int32_t* count, size_t buf_len, const dray_opts* opts, dray_stats* stats);
 
+/* The same call over several GPUs of one node from one process, as the single render call of main.rs:86 needs it
+ * (the reference spreads a frame over machines through src/distributed; orchestrator_server.rs:59-68 deals the
+ * rays out, :253-256 collects the pixels): entry k of `devices` renders scanlines k, k + n_devices, ... with the
+ * whole scene replicated, one host thread per entry, and writes its rows straight into the caller's buffers.
+ * Buffers, result and statistics are those of dray_render (kernel_ms: the slowest share).  devices == NULL means
+ * devices 0 .. n_devices-1; n_devices <= 0 means every visible GPU; a device may be named more than once.
+ * opts->device, row_begin, row_step and DRAY_FLAG_COMPACT_ROWS must be left at their defaults. */
+int dray_render_multi(const dray_camera* cam, const dray_sphere* spheres, size_t n_spheres, uint32_t* color, double* raw,
+                      int32_t* count, size_t buf_len, const dray_opts* opts, const int32_t* devices, int32_t n_devices,
+                      dray_stats* stats);
+
 /* ---- device-resident variant (buffers already in HBM) --------------------- */
 /* Upload the sphere list of a HittableList (hittable_list.rs:7-9) to `device`. */
 int dray_scene_create(const dray_sphere* spheres, size_t n_spheres, int32_t device, dray_scene** out);

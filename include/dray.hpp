@@ -157,6 +157,9 @@ class Camera {
     // > 0: render in passes of this many samples per pixel and call `present` after each pass; the buffers end up
     // the same as after one pass of samples_per_pixel
     int32_t samples_per_pass = 0;
+    // GPUs of this node to spread a render over from this one process (dray_render_multi); empty: the one device of
+    // `opts`.  A device may appear more than once.
+    std::vector<int32_t> devices;
     dray_stats last_stats{}; // of the whole call (counts and times summed over its passes)
 
     Camera() { dray_opts_default(&opts); }
@@ -208,9 +211,12 @@ class Camera {
             c.samples_per_pixel = total > 0 && total - done < per_pass ? total - done : per_pass;
             o.sample_offset = opts.sample_offset + (uint32_t)done;
             dray_stats st{};
-            check(dray_render(&c, spheres.empty() ? nullptr : spheres.data(), spheres.size(), color_buffer.data(),
-                              raw_buffer.empty() ? nullptr : raw_buffer.data(),
-                              count_buffer.empty() ? nullptr : count_buffer.data(), buf_len, &o, &st),
+            const dray_sphere* sp = spheres.empty() ? nullptr : spheres.data();
+            double* rawp = raw_buffer.empty() ? nullptr : raw_buffer.data();
+            int32_t* cntp = count_buffer.empty() ? nullptr : count_buffer.data();
+            check(devices.empty() ? dray_render(&c, sp, spheres.size(), color_buffer.data(), rawp, cntp, buf_len, &o, &st)
+                                  : dray_render_multi(&c, sp, spheres.size(), color_buffer.data(), rawp, cntp, buf_len, &o,
+                                                      devices.data(), (int32_t)devices.size(), &st),
                   "Camera::render");
             if (done == 0) {
                 whole = st;

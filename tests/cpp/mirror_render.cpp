@@ -63,6 +63,17 @@ int main(int argc, char** argv) {
             if (color3 != color || raw3 != raw || count3 != count) return 76;
             if (cam.last_stats.segments != first.segments || cam.last_stats.samples != first.samples) return 77;
         }
+        // the same frame again as three shares of interleaved scanlines on the one GPU (dray_render_multi)
+        {
+            std::vector<uint32_t> color4((size_t)W * W, 0u);
+            std::vector<double> raw4((size_t)W * W * 3, 0.0);
+            std::vector<int32_t> count4((size_t)W * W, 0);
+            cam.devices = {0, 0, 0};
+            cam.render(world, color4, raw4, count4);
+            cam.devices.clear();
+            if (color4 != color || raw4 != raw || count4 != count) return 80;
+            if (cam.last_stats.segments != first.segments || cam.last_stats.rows_rendered != H) return 81;
+        }
         // the same frame again through the resumable path state: rays for every (pixel, sample), stepped until all
         // are finished, colours summed per pixel in sample order (left-to-right product, camera.rs:118-144)
         unsigned long long step_segments = 0;

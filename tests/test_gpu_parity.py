@@ -568,6 +568,42 @@ def test_progressive_passes_equal_one_pass(dray, gpu):
             assert r[3] == results[0][3]
 
 
+def test_render_over_several_devices_equals_one(dray, gpu):
+    """dray_render_multi: the frame as interleaved-scanline shares, one host thread per share, each share written
+    straight into the caller's rows.  With every share on the one GPU of this box the buffers must equal dray_render's
+    bit for bit -- f64 and f32 modes, accumulating across two calls into the caller's W x W buffers, with an image
+    height that the share count does not divide."""
+    world = dray.scene_final(1)
+    for mode in (dray.MODE_F64, dray.MODE_F32):
+        results = []
+        for devices in (None, [0], [0, 0], [0, 0, 0, 0, 0], "all"):
+            cam = dray.camera_final(width=80, spp=3, depth=8)   # 80 x 45
+            cam.mode, cam.seed, cam.devices = mode, 12, devices
+            W = 80
+            color = np.full(W * W, 0xDEADBEEF, np.uint32)
+            raw, count = np.zeros((W * W, 3), np.float64), np.zeros(W * W, np.int32)
+            cam.render(world, None, color, raw, count)
+            cam.sample_offset = 3
+            cam.render(world, None, color, raw, count)
+            H = cam.image_height
+            assert H == 45 and (color[W * H:] == 0xDEADBEEF).all() and (count[:W * H] == 6).all() and (count[W * H:] == 0).all()
+            assert cam.last_stats.rows_rendered == H and cam.last_stats.samples == 3 * W * H
+            results.append((color, raw, count, cam.last_stats.segments))
+        for r in results[1:]:
+            assert (r[0] == results[0][0]).all() and (r[1] == results[0][1]).all() and (r[2] == results[0][2]).all()
+            assert r[3] == results[0][3]
+    cam = dray.camera_final(width=32, spp=1, depth=4)
+    color = np.zeros(32 * 32, np.uint32)
+    for bad in ([1], [-1], [0] * 65):   # this box has one GPU
+        cam.devices = bad
+        with pytest.raises(dray.DrayError) as e:
+            cam.render(world, None, color, None, None)
+        assert e.value.status == dray._ffi.ERR_INVALID_ARG
+    cam.devices = [0, 0]
+    with pytest.raises(dray.DrayError):   # the row partition is the call's own
+        cam.render(world, None, color, None, None, row_begin=1, row_step=2)
+
+
 def test_iterate_rays_is_one_shuffled_pass(dray, gpu, oracle):
     """Camera::iterate_rays (camera.rs:68-116, :165): image_width * image_height items, every pixel once, sample
     number 0, not in scan order; each item is the oracle's camera ray for that pixel."""

@@ -118,6 +118,11 @@ def test_no_gpu_means_loud_failure(dray):
         cam.render(dray.scene_three_spheres(), None, buf, None, None)
     assert e.value.status == -4
     assert (buf == 0).all()
+    for devices in ([0], [0, 1], "all"):   # the several-GPU call likewise
+        cam.devices = devices
+        with pytest.raises(dray.DrayError) as e:
+            cam.render(dray.scene_three_spheres(), None, buf, None, None)
+        assert e.value.status == -4 and (buf == 0).all()
 
 
 def test_partition_arithmetic(dray):
