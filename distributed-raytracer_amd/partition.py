@@ -62,6 +62,22 @@ def gather_image(slab, image_height, group=None, always_collective=False):
     return deinterleave(gathered.view(G, S, W), image_height, G)
 
 
+def gather_slabs(slab, image_height, group=None):
+    """All-gather per-rank slabs [slab_rows, W, ...] of any trailing shape (the running sums [.., 3], the counts) and
+    return the de-interleaved [H, W, ...] array on every rank."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return slab[:image_height]
+    G = dist.get_world_size(group)
+    S, W = slab.shape[0], slab.shape[1]
+    tail = tuple(slab.shape[2:])
+    gathered = torch.empty((G * S, W) + tail, dtype=slab.dtype, device=slab.device)
+    dist.all_gather_into_tensor(gathered, slab.contiguous(), group=group)
+    full = gathered.view((G, S, W) + tail).transpose(0, 1).reshape((S * G, W) + tail)  # row s*G + r = image row s*G + r
+    return full[:image_height]
+
+
 class DistributedRenderer:
     """Renders this rank's scanlines into persistent slab buffers and gathers the image.
 
@@ -88,6 +104,14 @@ class DistributedRenderer:
         self.samples_done += self.cam.samples_per_pixel
         image = gather_image(self.color, self.H, self.group) if gather else None
         return image, stats
+
+    def gather_sums(self):
+        """The other two buffers of the render call (camera.rs:212-213) for the whole image on every rank: the running
+        colour sums [H, W, 3] and sample counts [H, W] (colors.rs:38-39), gathered from the ranks' slabs.  Two more
+        all-gathers (6 x the colour's bytes + 1 x): asked for when needed, not every pass."""
+        if self.raw is None or self.count is None:
+            raise ValueError("this renderer was made without raw / count buffers")
+        return gather_slabs(self.raw, self.H, self.group), gather_slabs(self.count, self.H, self.group)
 
 
 def gpu_render_rows(scene, **opt_overrides):

@@ -63,6 +63,9 @@ def _worker(rank, world, port, out_dir):
     segs = torch.tensor([float(st1.segments + st2.segments)], dtype=torch.float64)
     dist.all_reduce(segs)
     np.save(os.path.join(out_dir, "img_rank%d.npy" % rank), img2.numpy().view(np.uint32))
+    raw_full, count_full = r.gather_sums()
+    np.save(os.path.join(out_dir, "raw_rank%d.npy" % rank), raw_full.numpy())
+    np.save(os.path.join(out_dir, "count_rank%d.npy" % rank), count_full.numpy())
     if rank == 0:
         np.save(os.path.join(out_dir, "segs.npy"), segs.numpy())
     dist.barrier()
@@ -81,4 +84,7 @@ def test_two_rank_gather_equals_single_render(tmp_path, world):
         img = np.load(os.path.join(str(tmp_path), "img_rank%d.npy" % rank))
         assert img.shape == col.shape
         assert (img == col).all()           # every rank holds the whole image, equal to the one-process render
+        # ... and, when asked, the running sums and counts of the whole image (colors.rs:38-39)
+        assert (np.load(os.path.join(str(tmp_path), "raw_rank%d.npy" % rank)) == raw).all()
+        assert (np.load(os.path.join(str(tmp_path), "count_rank%d.npy" % rank)) == cnt).all()
     assert int(np.load(os.path.join(str(tmp_path), "segs.npy"))[0]) == st.segments
