@@ -717,12 +717,22 @@ int render_multi_impl(const dray_camera* cam, const dray_sphere* spheres, size_t
     std::vector<int> rcs((size_t)G, DRAY_OK);
     std::vector<std::string> detail((size_t)G);
     std::vector<std::thread> workers;
-    for (int32_t g = 0; g < G; ++g)
+    workers.reserve((size_t)G);
+    bool started_all = true;
+    for (int32_t g = 0; g < G && started_all; ++g) try {
         workers.emplace_back([&, g]() {
-            rcs[g] = render_share(cam, spheres, n, color, raw, count, opts, devs[g], g, G, W, H, &st[g]);
-            if (rcs[g]) detail[g] = g_detail; // the failure text lives in the worker's thread
+            try { // nothing may leave a thread by unwinding
+                rcs[g] = render_share(cam, spheres, n, color, raw, count, opts, devs[g], g, G, W, H, &st[g]);
+                if (rcs[g]) detail[g] = g_detail; // the failure text lives in the worker's thread
+            } catch (...) {
+                rcs[g] = DRAY_ERR_INTERNAL;
+            }
         });
+    } catch (...) { // no thread to be had: wait for those that did start, then give up
+        started_all = false;
+    }
     for (auto& w : workers) w.join();
+    if (!started_all) return DRAY_ERR_INTERNAL;
     for (int32_t g = 0; g < G; ++g)
         if (rcs[g]) {
             snprintf(g_detail, sizeof g_detail, "device %d: %s", devs[g], detail[g].c_str());
