@@ -642,12 +642,24 @@ int render_share(const dray_camera* cam, const dray_sphere* spheres, size_t n, u
     };
     auto fail = [&](hipError_t e, const char* what) { int r = hip_fail(e, what); cleanup(); return r; };
     const size_t slab = n_rows * W;
-    // image row share + k * n_shares <-> slab row k
+    // image row share + k * n_shares <-> slab row k.  The rows are gathered into (scattered from) one contiguous
+    // staging block on the host and cross the bus in one copy: a strided hipMemcpy2D from pageable memory goes row
+    // by row (675 rows x 5 copies took 27 ms, as long as the render itself).
+    std::vector<char> stage;
     auto rows = [&](void* dev, void* host, size_t elem, hipMemcpyKind kind) {
         char* h = (char*)host + (size_t)share * W * elem;
-        const size_t host_pitch = (size_t)n_shares * W * elem, dev_pitch = W * elem;
-        return kind == hipMemcpyHostToDevice ? hipMemcpy2D(dev, dev_pitch, h, host_pitch, W * elem, n_rows, kind)
-                                             : hipMemcpy2D(h, host_pitch, dev, dev_pitch, W * elem, n_rows, kind);
+        const size_t row = W * elem, host_pitch = (size_t)n_shares * row;
+        if (n_shares == 1) return hipMemcpy(kind == hipMemcpyHostToDevice ? dev : (void*)h,
+                                            kind == hipMemcpyHostToDevice ? (const void*)h : dev, n_rows * row, kind);
+        stage.resize(n_rows * row);
+        if (kind == hipMemcpyHostToDevice) {
+            for (size_t k = 0; k < n_rows; ++k) std::memcpy(stage.data() + k * row, h + k * host_pitch, row);
+            return hipMemcpy(dev, stage.data(), n_rows * row, kind);
+        }
+        const hipError_t e = hipMemcpy(stage.data(), dev, n_rows * row, kind);
+        if (e == hipSuccess)
+            for (size_t k = 0; k < n_rows; ++k) std::memcpy(h + k * host_pitch, stage.data() + k * row, row);
+        return e;
     };
     hipError_t e;
     if ((e = hipMalloc((void**)&d_color, slab * sizeof(uint32_t))) != hipSuccess) return fail(e, "hipMalloc color");
