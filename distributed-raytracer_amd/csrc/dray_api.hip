@@ -462,6 +462,33 @@ int scene_create_impl(const dray_sphere* sp, size_t n, int32_t device, dray_scen
     d.f32.kind = d.kind;
     d.f32.n_narrow_padded = d.n_narrow_padded;
     d.f32.n_wide = d.n_wide;
+    { // the ball the f32 kernel moves a far ray's origin up to: centre of the narrow spheres' box, farthest reach
+        double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        auto finite = [&](int32_t p) {
+            return std::isfinite(ng[4 * p]) && std::isfinite(ng[4 * p + 1]) && std::isfinite(ng[4 * p + 2]) &&
+                   std::isfinite(ng[4 * p + 3]);
+        };
+        for (int32_t p = 0; p < d.n_narrow; ++p)
+            if (finite(p))
+                for (int q = 0; q < 3; ++q) {
+                    lo[q] = std::fmin(lo[q], (double)ng[4 * p + q]);
+                    hi[q] = std::fmax(hi[q], (double)ng[4 * p + q]);
+                }
+        if (lo[0] <= hi[0]) {
+            double reach = 0.;
+            for (int32_t p = 0; p < d.n_narrow; ++p)
+                if (finite(p)) {
+                    double d2 = 0.;
+                    for (int q = 0; q < 3; ++q) {
+                        const double v = (double)ng[4 * p + q] - 0.5 * (lo[q] + hi[q]);
+                        d2 += v * v;
+                    }
+                    reach = std::fmax(reach, std::sqrt(d2) + std::sqrt((double)ng[4 * p + 3]));
+                }
+            for (int q = 0; q < 3; ++q) d.f32.bound[q] = (float)(0.5 * (lo[q] + hi[q]));
+            d.f32.bound[3] = (float)(1.01 * reach + 1e-6 * (std::fabs(d.f32.bound[0]) + std::fabs(d.f32.bound[1]) + std::fabs(d.f32.bound[2])) + 1e-30);
+        }
+    }
     hipError_t e = hipMalloc((void**)&s->d_counters, sizeof(DeviceCounters));
     for (auto& ev : s->ev)
         if (e == hipSuccess) e = hipEventCreate(&ev);

@@ -44,6 +44,8 @@ struct F32Tables {
     const uint32_t* kind = nullptr;        // n: material kind
     int32_t n_narrow_padded = 0;
     int32_t n_wide = 0;
+    // a ball (centre, radius with 1 % to spare) that holds every finite narrow sphere; radius inf: none to hold
+    float bound[4] = {0.f, 0.f, 0.f, INFINITY};
 };
 
 // Uniform grid over the narrow spheres, walked by the f32 kernel's grid scan.  A sphere is entered in every cell

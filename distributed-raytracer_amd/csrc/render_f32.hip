@@ -400,6 +400,7 @@ struct F32Args {
     const V4* mat32;
     const uint32_t* kind;
     int32_t n_narrow_padded, n_wide;
+    float bound[4]; // F32Tables::bound
     GridDev grid;
     Partition part;
     RngKey key;
@@ -523,13 +524,27 @@ __device__ __forceinline__ void render_f32_body() {
         // ---- closest hit over the sphere list: hittable_list.rs:60-74 ---------------------------
         n_seg += (unsigned long long)__popcll(__ballot(fresh));
         if (fresh) {
+            // The origin moves along the ray up to the ball that holds the narrow spheres (the ray's parameters,
+            // tmin included, move with it).  The exact test takes |oc|^2 from r^2, and seen from far away -- a bounce
+            // off a huge enclosing sphere, a distant camera -- r^2 is lost in the rounding of |oc|^2: the test then
+            // accepts spheres the ray passes at a distance (0.02 units at |oc| = 50), and which of those a scan meets
+            // depends on the scan.  From the ball's rim |oc| is at most its diameter.  Nothing narrow lies before the
+            // rim, so the narrow tests may take max(tmin, 0) for their lower bound; the wide spheres keep tmin.
+            {
+                const float bx = a->bound[0] - ray.o.x, by = a->bound[1] - ray.o.y, bz = a->bound[2] - ray.o.z;
+                const float s = fmaxf(fmaf(bz, ray.d.z, fmaf(by, ray.d.y, bx * ray.d.x)) - a->bound[3], 0.f);
+                ray.o = {fmaf(s, ray.d.x, ray.o.x), fmaf(s, ray.d.y, ray.o.y), fmaf(s, ray.d.z, ray.o.z)};
+                ray.tmin -= s;
+            }
+            PathRay nray = ray;
+            nray.tmin = fmaxf(ray.tmin, 0.f);
             sb = {INFINITY, -1, false};
             if constexpr (SCAN == kScanHybrid)
-                scan_hybrid(lds_xy, as_constant(a->filter_zn), as_constant(a->narrow_geom), a->n_narrow_padded, ray, sb);
+                scan_hybrid(lds_xy, as_constant(a->filter_zn), as_constant(a->narrow_geom), a->n_narrow_padded, nray, sb);
             else if constexpr (SCAN == kScanGrid)
-                walking = walk_begin(&a->grid, as_constant(a->narrow_geom), ray, walk);
+                walking = walk_begin(&a->grid, as_constant(a->narrow_geom), nray, walk);
             else
-                scan_scalar(as_constant(a->narrow_geom), a->n_narrow_padded, ray, sb);
+                scan_scalar(as_constant(a->narrow_geom), a->n_narrow_padded, nray, sb);
             fresh = false;
         }
         if constexpr (SCAN == kScanGrid) {
@@ -537,9 +552,11 @@ __device__ __forceinline__ void render_f32_body() {
             const int quorum = exhausted ? 1 : kWalkQuorum;
             const GridRegs gr = {(float)a->grid.n[0], (float)a->grid.n[1], (float)a->grid.n[2], a->grid.cells,
                                  (const V4*)a->grid.entry_geom, a->grid.entry_pos};
+            PathRay nray = ray;
+            nray.tmin = fmaxf(ray.tmin, 0.f); // see the origin's move above
             do { // two steps per count: the count is scalar-unit work every walking lane waits for
-                if (walking) walking = walk_step(gr, ray, walk);
-                if (walking) walking = walk_step(gr, ray, walk);
+                if (walking) walking = walk_step(gr, nray, walk);
+                if (walking) walking = walk_step(gr, nray, walk);
                 n_steps += 2u;
             } while (__popcll(__ballot(walking)) >= quorum);
         }
@@ -906,6 +923,7 @@ hipError_t launch_render_f32(const CamDev<float>& cam, const SceneDev& scene, co
     args.narrow_index = t.narrow_index; args.wide_index = t.wide_index;
     args.geom64 = t.geom64; args.geom32 = (const V4*)t.geom32; args.mat32 = (const V4*)t.mat32; args.kind = t.kind;
     args.n_narrow_padded = t.n_narrow_padded; args.n_wide = t.n_wide;
+    for (int q = 0; q < 4; ++q) args.bound[q] = t.bound[q];
     args.grid = scene.grid;
     args.part = part; args.key = key; args.pixels_per_pool = plan.pixels_per_pool; args.grab_pixels = plan.grab_pixels;
     args.accum = d_accum; args.counters = d_counters;
