@@ -627,6 +627,52 @@ def test_f64_kernel_matches_oracle_on_random_scenes(dray, gpu, oracle):
     assert within / total >= 0.97 and abs(seg32 / seg64 - 1) < 0.02
 
 
+def test_f32_image_is_independent_of_scheduling_on_random_scenes(dray, gpu):
+    """30 random scenes, random frame sizes and sample counts (1 to 300 per pixel: every pooling regime of the
+    work queue): the f32 image and sums do not depend on the pool size, on the row partition (3 interleaved compact
+    slabs) or on splitting the samples over two calls."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from fuzz_scans import random_scene
+    rng = np.random.default_rng(9)
+    for k in range(30):
+        sp, cam, what = random_scene(rng, dray)
+        cam.image_width = int(rng.choice([8, 33, 48, 130]))
+        cam.samples_per_pixel = int(rng.choice([1, 2, 7, 40, 64, 129, 300]))
+        scene = gpu.DeviceScene(sp, 0)
+        color, raw, count = gpu.alloc_buffers(cam, 0)
+        whole = gpu.render_device(cam, scene, color, raw, count)
+        ref = (gpu.color_to_numpy(color).copy(), raw.cpu().numpy().copy())
+        H, W = cam.image_height, cam.image_width
+        for ppp in (1, 5, 16):
+            color, raw, count = gpu.alloc_buffers(cam, 0)
+            st = gpu.render_device(cam, scene, color, raw, count, pixels_per_pool=ppp)
+            assert (gpu.color_to_numpy(color) == ref[0]).all() and (raw.cpu().numpy() == ref[1]).all(), (k, what, ppp)
+            assert st.segments == whole.segments
+        got_c, got_r, segs = np.zeros_like(ref[0]), np.zeros_like(ref[1]), 0
+        for g in range(3):
+            color, raw, count = gpu.alloc_buffers(cam, 0)
+            st = gpu.render_device(cam, scene, color, raw, count, row_begin=g, row_step=3, flags=dray.FLAG_COMPACT_ROWS)
+            rows = len(range(g, H, 3))
+            got_c.reshape(-1, W)[g:H:3] = gpu.color_to_numpy(color).reshape(-1, W)[:rows]
+            got_r.reshape(-1, W, 3)[g:H:3] = raw.cpu().numpy().reshape(-1, W, 3)[:rows]
+            segs += st.segments
+        assert (got_c.reshape(-1, W)[:H] == ref[0].reshape(-1, W)[:H]).all(), (k, what)
+        assert (got_r.reshape(-1, W, 3)[:H] == ref[1].reshape(-1, W, 3)[:H]).all() and segs == whole.segments, (k, what)
+        if cam.samples_per_pixel > 1:
+            spp, first = cam.samples_per_pixel, cam.samples_per_pixel // 3 + 1
+            color, raw, count = gpu.alloc_buffers(cam, 0)
+            cam.samples_per_pixel = first
+            a = gpu.render_device(cam, scene, color, raw, count)
+            cam.samples_per_pixel = spp - first
+            b = gpu.render_device(cam, scene, color, raw, count, sample_offset=first)
+            cam.samples_per_pixel = spp
+            assert (gpu.color_to_numpy(color) == ref[0]).all() and (raw.cpu().numpy() == ref[1]).all(), (k, what)
+            assert a.segments + b.segments == whole.segments
+        scene.close()
+
+
 def test_render_over_several_devices_equals_one(dray, gpu):
     """dray_render_multi: the frame as interleaved-scanline shares, one host thread per share, each share written
     straight into the caller's rows.  With every share on the one GPU of this box the buffers must equal dray_render's
