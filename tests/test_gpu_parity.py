@@ -765,6 +765,31 @@ def test_path_step_matches_oracle(dray, gpu, oracle):
     assert (total == raw).all()
 
 
+def test_path_step_matches_oracle_on_random_scenes(dray, gpu, oracle):
+    """The resumable path state on 25 random scenes: 300 random (pixel, sample) entries each, stepped to the end; every
+    byte of every entry equals the oracle's after every step."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from fuzz_scans import random_scene
+    rng = np.random.default_rng(13)
+    for k in range(25):
+        sp, cam, what = random_scene(rng, dray)
+        cam.mode = dray.MODE_F64
+        H, W = cam.initialize().image_height, cam.image_width
+        px = np.stack([rng.integers(0, W, 300), rng.integers(0, H, 300), rng.integers(0, 50, 300)], axis=1).astype(np.int32)
+        e = gpu.camera_rays(cam, px)
+        oe = oracle.camera_ray_entries(ocam_from(oracle, cam), px, seed=cam.seed)
+        assert e.tobytes() == oe.tobytes(), (k, what)
+        scene = gpu.DeviceScene(sp, 0)
+        for step in range(cam.max_depth + 2):
+            gpu.ray_color_iteration(e, scene, cam)
+            oracle.ray_color_iteration(oe, sp, W, seed=cam.seed)
+            assert e.tobytes() == oe.tobytes(), (k, what, step)
+        assert (e["finished"] == 1).all()
+        scene.close()
+
+
 def test_rccl_gather_on_one_gpu(dray, gpu):
     """The collective of the multi-GPU path (one all_gather_into_tensor of the packed int32 slabs over the "nccl"
     backend = RCCL) run on a one-rank group: the gathered image equals the plain render."""
