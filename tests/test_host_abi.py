@@ -218,7 +218,12 @@ def test_grid_lists_every_sphere_wherever_its_ball_reaches(dray):
     cloud["radius"][1] = 500.0   # wide
     cloud["center"][2] = (np.nan, 0, 0)  # not finite: loose
     cloud["kind"] = 1
-    for spheres in (dray.scene_final(1), dray.scene_grid_10k(2)[::5], cloud):
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from fuzz_scans import random_scene   # the generator of the GPU fuzz tests: layouts, scales, offsets, outsized spheres
+    frng = np.random.default_rng(21)
+    fuzz = [random_scene(frng, dray)[0] for _ in range(25)]
+    for spheres in [dray.scene_final(1), dray.scene_grid_10k(2)[::5], cloud] + fuzz:
         info, cell_begin, entry, loose = dray.grid_inspect(spheres)
         n = np.array(list(info.n))
         assert (n >= 1).all() and (n <= 256).all()
