@@ -341,6 +341,8 @@ void classify_spheres(const dray_sphere* sp, size_t n, std::vector<float>& ng, s
 int grid_inspect_impl(const dray_sphere* sp, size_t n, dray_grid_info* info, uint32_t* cell_begin, int32_t* entry_sphere,
                       int32_t* loose_sphere) {
     if (!info || (!sp && n) || n > 0x7fffffffu) return DRAY_ERR_INVALID_ARG;
+    for (size_t k = 0; k < n; ++k) // the lists dray_scene_create takes, and no others
+        if (sp[k].kind > DRAY_MAT_DIELECTRIC) return DRAY_ERR_UNSUPPORTED;
     std::vector<float> ng;
     std::vector<int32_t> nidx, widx;
     classify_spheres(sp, n, ng, nidx, widx);

@@ -256,3 +256,58 @@ def test_grid_lists_every_sphere_wherever_its_ball_reaches(dray):
     assert 0 in loose.tolist() and 2 in loose.tolist()
     info, _, _, _ = dray.grid_inspect(np.zeros(0, dtype=dray._ffi.SPHERE_DTYPE))
     assert list(info.n) == [0, 0, 0] and info.n_entries == 0
+
+
+def test_entry_points_reject_bad_arguments(dray):
+    """Every entry point answers null pointers, non-positive sizes and out-of-range options with a status, never with
+    a crash (nothing may unwind or fault across the boundary: the reference aborts on panic, Cargo.toml:32-35)."""
+    from dray_amd import _ffi
+    L = _ffi.lib()
+    INV = _ffi.ERR_INVALID_ARG
+    cam, der, opts, st = _ffi.CameraPOD(), _ffi.CameraDerivedPOD(), _ffi.Opts(), _ffi.Stats()
+    L.dray_camera_default(C.byref(cam))
+    L.dray_opts_default(C.byref(opts))
+    assert L.dray_camera_initialize(None, C.byref(der)) == INV and L.dray_camera_initialize(C.byref(cam), None) == INV
+    bad = _ffi.CameraPOD.from_buffer_copy(cam)
+    for field, value in (("image_width", 0), ("image_width", -5), ("aspect_ratio", 0.0), ("aspect_ratio", float("nan")),
+                         ("aspect_ratio", float("inf")), ("aspect_ratio", -1.0)):
+        bad = _ffi.CameraPOD.from_buffer_copy(cam)
+        setattr(bad, field, value)
+        assert L.dray_camera_initialize(C.byref(bad), C.byref(der)) == INV, (field, value)
+    color = np.zeros(100 * 100, np.uint32)
+    sp = dray.scene_three_spheres()
+    n = len(sp)
+    # the render calls: argument checks come before any device is touched
+    assert L.dray_render(None, sp.ctypes.data, n, color.ctypes.data, None, None, color.size, C.byref(opts), None) == INV
+    assert L.dray_render(C.byref(cam), sp.ctypes.data, n, None, None, None, color.size, C.byref(opts), None) == INV
+    assert L.dray_render(C.byref(cam), None, n, color.ctypes.data, None, None, color.size, C.byref(opts), None) == INV
+    assert L.dray_render_multi(None, sp.ctypes.data, n, color.ctypes.data, None, None, color.size, C.byref(opts), None, 0, None) == INV
+    assert L.dray_render_multi(C.byref(cam), None, n, color.ctypes.data, None, None, color.size, C.byref(opts), None, 0, None) == INV
+    strided = _ffi.Opts.from_buffer_copy(opts)
+    strided.row_step = 2
+    assert L.dray_render_multi(C.byref(cam), sp.ctypes.data, n, color.ctypes.data, None, None, color.size, C.byref(strided), None, 0, None) == INV
+    handle = C.c_void_p()
+    assert L.dray_scene_create(None, 3, -1, C.byref(handle)) in (INV, _ffi.ERR_NO_DEVICE) and not handle.value
+    assert L.dray_scene_create(sp.ctypes.data, n, -1, None) == INV
+    L.dray_scene_destroy(None)   # a no-op, like free(NULL)
+    assert L.dray_render_device(C.byref(cam), None, color.ctypes.data, None, None, color.size, C.byref(opts), None, None) == INV
+    assert L.dray_camera_rays(None, None, 1, None, None) == INV
+    assert L.dray_path_step(None, 10, None, 1, None, None) == INV
+    assert L.dray_camera_rays_device(None, None, 1, None, None, None) == INV
+    assert L.dray_path_step_device(None, 10, None, 1, None, None) == INV
+    info = _ffi.GridInfo()
+    assert L.dray_grid_inspect(None, 3, C.byref(info), None, None, None) == INV
+    assert L.dray_grid_inspect(sp.ctypes.data, n, None, None, None, None) == INV
+    unknown = sp.copy()
+    unknown["kind"][1] = 9
+    assert L.dray_grid_inspect(unknown.ctypes.data, n, C.byref(info), None, None, None) == _ffi.ERR_UNSUPPORTED
+    TOO_SMALL = _ffi.ERR_BUFFER_TOO_SMALL   # no room to write to, a null buffer included
+    assert L.dray_scene_three_spheres(None, 4) == TOO_SMALL and L.dray_scene_three_spheres(sp.ctypes.data, 2) == TOO_SMALL
+    assert L.dray_scene_final(1, None, 1000) == TOO_SMALL and L.dray_scene_final(1, sp.ctypes.data, n) == TOO_SMALL
+    assert L.dray_scene_recipe(1, 5, 4, 0.8, 0.15, 0.5, sp.ctypes.data, n) == INV            # hi < lo
+    assert L.dray_scene_recipe(1, 5, 5, 0.8, 0.15, 0.5, sp.ctypes.data, n) == 4              # no cells: ground + the three large spheres
+    assert L.dray_write_ppm(None, color.ctypes.data, 10, 10, 0) == INV
+    assert L.dray_write_ppm(b"/tmp/x.ppm", None, 10, 10, 0) == INV
+    assert L.dray_write_ppm(b"/tmp/x.ppm", color.ctypes.data, 0, 10, 0) == INV
+    L.dray_opts_default(None)
+    L.dray_camera_default(None)
