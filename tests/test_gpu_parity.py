@@ -367,6 +367,26 @@ def test_error_paths(dray, gpu):
     assert e.value.status == -3
     cam.flags = dray.FLAG_ITERATIVE_PRODUCT
     cam.render(spheres, None, buf, None, None)
+    # the device-resident call: options out of range, a slab too small, a scan the scene is too large for
+    cam = dray.camera_three_spheres(width=32, spp=1, depth=5)
+    scene = gpu.DeviceScene(spheres, 0)
+    color, raw, count = gpu.alloc_buffers(cam, 0)
+    for kw, status in ((dict(variant=9), -1), (dict(variant=-1), -1), (dict(mode=7), -1), (dict(row_step=-2), -1),
+                       (dict(row_begin=-1), -1)):
+        with pytest.raises(dray.DrayError) as e:
+            gpu.render_device(cam, scene, color, raw, count, **kw)
+        assert e.value.status == status, kw
+    with pytest.raises(dray.DrayError) as e:
+        gpu.render_device(cam, scene, color[:4], raw, count)
+    assert e.value.status == -2
+    scene.close()
+    many = dray.scene_grid_10k(2)   # 10 001 spheres: beyond the hybrid scan's LDS table
+    scene = gpu.DeviceScene(many, 0)
+    with pytest.raises(dray.DrayError) as e:
+        gpu.render_device(cam, scene, color, raw, count, variant=dray.SCAN_HYBRID)
+    assert e.value.status == -3
+    gpu.render_device(cam, scene, color, raw, count)   # the default scan takes it
+    scene.close()
 
 
 def test_edge_cases(dray, gpu, oracle):
