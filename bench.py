@@ -90,9 +90,18 @@ def main():
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
                          % (args.gpus, world, args.gpus))
+    # Rehearsal on a box with fewer GPUs than ranks (never what the driver runs): DRAY_BENCH_REHEARSAL=1 puts every
+    # rank on GPU 0 and swaps RCCL, which refuses two ranks on one device, for gloo; the gather is then staged
+    # through host memory (partition.gather_image) and the timings mean nothing.
+    rehearsal = os.environ.get("DRAY_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     spheres = d.scene_final(args.seed)
     cam = d.camera_final(width=args.width, spp=args.spp, depth=args.depth)
@@ -123,7 +132,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
 
-    tot = torch.tensor([float(segs), float(samples), elapsed], dtype=torch.float64, device="cuda")
+    tot = torch.tensor([float(segs), float(samples), elapsed], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
     if world > 1:
         sums = tot.clone()
         dist.all_reduce(sums, op=dist.ReduceOp.SUM)

@@ -57,6 +57,11 @@ def gather_image(slab, image_height, group=None, always_collective=False):
         return slab[:image_height]
     G = dist.get_world_size(group)
     S, W = slab.shape
+    if slab.is_cuda and dist.get_backend(group) == "gloo":
+        # gloo gathers host tensors only: stage through host memory (rehearsals of the multi-rank path on one GPU)
+        host = torch.empty((G * S, W), dtype=slab.dtype)
+        dist.all_gather_into_tensor(host, slab.contiguous().cpu(), group=group)
+        return deinterleave(host.to(slab.device).view(G, S, W), image_height, G)
     gathered = torch.empty((G * S, W), dtype=slab.dtype, device=slab.device)  # rank r's slab = rows r*S .. r*S+S-1
     dist.all_gather_into_tensor(gathered, slab.contiguous(), group=group)
     return deinterleave(gathered.view(G, S, W), image_height, G)

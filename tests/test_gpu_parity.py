@@ -810,6 +810,35 @@ def test_path_step_matches_oracle_on_random_scenes(dray, gpu, oracle):
         scene.close()
 
 
+def test_bench_two_ranks_rehearsal(dray, gpu):
+    """bench.py the way the driver launches it for N > 1 (torch.distributed.run, one process per rank), rehearsed
+    with two ranks on this box's one GPU: DRAY_BENCH_REHEARSAL=1 swaps RCCL (which refuses two ranks on a device) for
+    gloo, everything else is the measured path.  One JSON line from rank 0, whole-job totals over both ranks."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, DRAY_BENCH_REHEARSAL="1")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+                        "--gpus", "2", "--steps", "2", "--warmup", "1", "--width", "160", "--spp", "8",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=110, env=env, cwd=root)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1 and out["scaling"] == "strong"
+    assert out["value"] > 0 and out["roofline"]["kernel_ms"] > 0
+    samples = out["samples_per_s"] * out["ms_per_step"] * 1e-3 * out["steps"]
+    assert abs(samples - 160 * 90 * 8 * 2) < 1.0   # both ranks' rows, both steps
+
+
 def test_rccl_gather_on_one_gpu(dray, gpu):
     """The collective of the multi-GPU path (one all_gather_into_tensor of the packed int32 slabs over the "nccl"
     backend = RCCL) run on a one-rank group: the gathered image equals the plain render."""
