@@ -3,19 +3,22 @@
 // One persistent launch.  Every lane carries one path; the recursion of the
 // reference's ray_color (src/raytracer/camera.rs:264-282) is the iterative
 // bounce loop of its twin ray_color_iteration (camera.rs:118-144) with an
-// explicit throughput.  When a lane's path ends it starts the next sample of
-// its work item, and when the item is used up it takes the next item of the
-// wave's pool, so all 64 lanes stay inside the sphere scan, which is the same
-// instruction stream for every lane whatever its pixel, sample or bounce.
+// explicit throughput.  A wave draws whole pixels from a global queue and hands
+// their samples to its lanes one at a time: when a lane's path ends it takes
+// the pool's next sample, so all 64 lanes stay busy whatever their pixel,
+// sample or bounce.
 //
 // Sample colours are summed as 36.28 fixed-point integers (integer addition is
 // associative), so the image does not depend on how samples are grouped, on
 // the partition, the GPU count or the order in which lanes finish.
 //
-// The sphere list is scanned in insertion order (hittable_list.rs:65-70).
-// "Narrow" spheres are tested in f32; "wide" spheres, whose radius is so large
-// that |oc|^2 - r^2 cancels catastrophically in f32 (the 1000-radius ground of
-// src/main.rs:14), are tested in f64.
+// The closest hit is the one the reference's scan of the list in insertion
+// order finds (hittable_list.rs:65-70: smallest t, on equal t the sphere
+// inserted first), whichever of the three scans below looks for it: the test
+// of every sphere, the same behind a cheap filter, or a walk through a uniform
+// grid.  "Narrow" spheres are tested in f32; "wide" spheres, whose radius is
+// so large that |oc|^2 - r^2 cancels catastrophically in f32 (the 1000-radius
+// ground of src/main.rs:14), are tested in f64.
 //
 // What bounds the scan on this chip (tools/ubench_operand.hip, tools/ubench_valu.hip): a VALU operation whose
 // operands are all VGPRs costs ~2.2 cycles of a SIMD, one with an SGPR (or DPP) operand ~3.6 cycles of the
@@ -47,7 +50,7 @@ constexpr int kWalkQuorum = DRAY_WALK_QUORUM;     // grid scan: lanes that must 
 
 // Waves per SIMD the register allocation of the brute-force kernels aims at (8 = at most 64 VGPRs; hybrid scan,
 // 1200x675x500 frame: 7 -> 96.4 ms, 8 -> 93.8 ms) and of the grid kernel, which keeps a lane's walk alive across
-// the main loop and wants more registers per lane (4 -> 50.2 ms, 5 -> 45.0 ms, 6 -> 43.6 ms).
+// the main loop and wants more registers per lane (5 -> 28.8 ms, 6 -> 27.3 ms, 7 -> 27.6 ms with 24 spilled registers).
 #ifndef DRAY_WAVES_PER_EU
 #define DRAY_WAVES_PER_EU 8
 #endif
