@@ -254,6 +254,16 @@ class DeviceScene {
     dray_scene* scene_ = nullptr;
 };
 
+// Camera::render with the world already uploaded and the three buffers in that GPU's memory (device pointers,
+// buf_len pixels each; d_raw and d_count may be null): nothing crosses the bus.  Enqueues on `stream` (a
+// hipStream_t, null = the default stream); blocks only when `stats` is asked for.
+inline void render_device(const Camera& cam, const DeviceScene& world, uint32_t* d_color, double* d_raw, int32_t* d_count,
+                          size_t buf_len, void* stream = nullptr, dray_stats* stats = nullptr) {
+    const dray_camera c = cam.pod();
+    check(dray_render_device(&c, world.handle(), d_color, d_raw, d_count, buf_len, &cam.opts, stream, stats),
+          "render_device");
+}
+
 using PixelIndexEntry = dray_pixel_index; // camera.rs:8-13
 using RayColorEntry = dray_path_entry;    // camera.rs:15-38 (entry and status in one record)
 
