@@ -828,8 +828,12 @@ int path_step_device_impl(dray_scene* scene, int32_t image_width, dray_path_entr
     if (g.err != hipSuccess) return hip_fail(g.err, "hipSetDevice");
     const RngKey key = {(uint32_t)opts.seed, (uint32_t)(opts.seed >> 32), opts.sample_offset};
     hipStream_t stream = (hipStream_t)stream_v;
-    if (count) HIP_TRY(hipMemsetAsync(scene->d_counters, 0, sizeof(DeviceCounters), stream));
+    if (count) {
+        HIP_TRY(hipMemsetAsync(scene->d_counters, 0, sizeof(DeviceCounters), stream));
+        HIP_TRY(hipEventRecord(scene->ev[0], stream));
+    }
     HIP_TRY(launch_path_step(scene->dev, key, image_width, d_entries, n, count ? scene->d_counters : nullptr, stream));
+    if (count) HIP_TRY(hipEventRecord(scene->ev[1], stream));
     return DRAY_OK;
 }
 
@@ -864,6 +868,7 @@ int camera_rays_host_impl(const dray_camera* cam, const dray_pixel_index* px, si
 
 int path_step_host_impl(dray_scene* scene, int32_t image_width, dray_path_entry* entries, size_t n,
                         const dray_opts* opts_in, dray_stats* stats) {
+    const auto t_begin = std::chrono::steady_clock::now();
     if (!scene || image_width < 1 || (n && !entries)) return DRAY_ERR_INVALID_ARG;
     if (stats) std::memset(stats, 0, sizeof *stats);
     DeviceGuard g(scene->device);
@@ -880,6 +885,10 @@ int path_step_host_impl(dray_scene* scene, int32_t image_width, dray_path_entry*
         HIP_TRY(hipMemcpy(&hc, scene->d_counters, sizeof hc, hipMemcpyDeviceToHost));
         stats->segments = hc.segments;
         stats->n_spheres = scene->dev.n;
+        float k_ms = 0.f; // the copies above have waited for the kernel
+        HIP_TRY(hipEventElapsedTime(&k_ms, scene->ev[0], scene->ev[1]));
+        stats->kernel_ms = k_ms;
+        stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     }
     return DRAY_OK;
 }
