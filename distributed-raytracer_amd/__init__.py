@@ -9,7 +9,7 @@ from ._ffi import (FLAG_COMPACT_ROWS, FLAG_ITERATIVE_PRODUCT, MODE_F32, MODE_F32
                    PATH_ENTRY_DTYPE, PIXEL_INDEX_DTYPE, SCAN_GRID, SCAN_HYBRID, SCAN_SCALAR, DrayError)
 from .raytracer import (Camera, DefaultMaterial, Dialectric, Hittable, HittableList, Lambertian, Material, Metal,  # noqa: F401
                         Sphere, camera_final, camera_three_spheres, flatten_world, grid_inspect, scene_final, scene_glass_metal,
-                        scene_grid_10k, scene_recipe, scene_three_spheres, write_ppm)
+                        scene_grid_10k, scene_recipe, scene_three_spheres, write_ppm, Transparent)
 
 
 def version():

@@ -23,7 +23,7 @@ ERR_NO_DEVICE = -4
 ERR_HIP = -5
 ERR_INTERNAL = -6
 
-MAT_DEFAULT, MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC = 0, 1, 2, 3
+MAT_DEFAULT, MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC, MAT_TRANSPARENT = 0, 1, 2, 3, 4
 MODE_F64, MODE_F32, MODE_F32_PLAIN = 0, 1, 2
 FLAG_ITERATIVE_PRODUCT = 1
 FLAG_COMPACT_ROWS = 2

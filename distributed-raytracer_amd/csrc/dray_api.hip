@@ -142,7 +142,7 @@ void scene_free(dray_scene* s) {
     if (!s) return;
     DeviceGuard g(s->device);
     SceneDev& d = s->dev;
-    (void)hipFree(d.geom64); (void)hipFree(d.mat64); (void)hipFree(d.kind);
+    (void)hipFree(d.geom64); (void)hipFree(d.mat64); (void)hipFree(d.kind); (void)hipFree(d.kind32);
     (void)hipFree(d.geom32); (void)hipFree(d.mat32);
     (void)hipFree(d.narrow_geom); (void)hipFree(d.filter_xy); (void)hipFree(d.filter_zn);
     (void)hipFree(d.narrow_index); (void)hipFree(d.wide_index);
@@ -342,7 +342,7 @@ int grid_inspect_impl(const dray_sphere* sp, size_t n, dray_grid_info* info, uin
                       int32_t* loose_sphere) {
     if (!info || (!sp && n) || n > 0x7fffffffu) return DRAY_ERR_INVALID_ARG;
     for (size_t k = 0; k < n; ++k) // the lists dray_scene_create takes, and no others
-        if (sp[k].kind > DRAY_MAT_DIELECTRIC) return DRAY_ERR_UNSUPPORTED;
+        if (sp[k].kind > DRAY_MAT_TRANSPARENT) return DRAY_ERR_UNSUPPORTED;
     std::vector<float> ng;
     std::vector<int32_t> nidx, widx;
     classify_spheres(sp, n, ng, nidx, widx);
@@ -379,7 +379,7 @@ int scene_create_impl(const dray_sphere* sp, size_t n, int32_t device, dray_scen
     if (device < 0) HIP_TRY(hipGetDevice(&device));
     if (device >= ndev) return DRAY_ERR_INVALID_ARG;
     for (size_t k = 0; k < n; ++k)
-        if (sp[k].kind > DRAY_MAT_DIELECTRIC) return DRAY_ERR_UNSUPPORTED;
+        if (sp[k].kind > DRAY_MAT_TRANSPARENT) return DRAY_ERR_UNSUPPORTED;
 
     DeviceGuard g(device);
     if (g.err != hipSuccess) return hip_fail(g.err, "hipSetDevice");
@@ -446,7 +446,14 @@ int scene_create_impl(const dray_sphere* sp, size_t n, int32_t device, dray_scen
     d.grid.entry_pos = d.grid_entry_pos;
     d.grid.loose = d.grid_loose;
     d.grid_entries = grid.entry_pos.size();
+    // The throughput kernel renders Transparent (material.rs:22-31) as the absorber it amounts to: the ray it hands
+    // back meets the same sphere again at every depth left and the sample comes out black.  (Only the statistics
+    // differ: that kernel counts one segment where the reference-order kernels walk through the depths left.)
+    std::vector<uint32_t> kind32(kind);
+    for (uint32_t& k : kind32)
+        if (k == DRAY_MAT_TRANSPARENT) k = DRAY_MAT_DEFAULT;
     if ((rc = upload(&d.geom64, g64)) || (rc = upload(&d.mat64, m64)) || (rc = upload(&d.kind, kind)) ||
+        (rc = upload(&d.kind32, kind32)) ||
         (rc = upload(&d.geom32, g32)) || (rc = upload(&d.mat32, m32)) || (rc = upload(&d.narrow_geom, ng)) ||
         (rc = upload(&d.filter_xy, fxy)) || (rc = upload(&d.filter_zn, fzn)) ||
         (rc = upload(&d.narrow_index, nidx)) || (rc = upload(&d.wide_index, widx))) {
@@ -461,7 +468,7 @@ int scene_create_impl(const dray_sphere* sp, size_t n, int32_t device, dray_scen
     d.f32.geom64 = d.geom64;
     d.f32.geom32 = (const float4*)d.geom32;
     d.f32.mat32 = (const float4*)d.mat32;
-    d.f32.kind = d.kind;
+    d.f32.kind = d.kind32;
     d.f32.n_narrow_padded = d.n_narrow_padded;
     d.f32.n_wide = d.n_wide;
     { // the ball the f32 kernel moves a far ray's origin up to: centre of the narrow spheres' box, farthest reach
@@ -737,7 +744,7 @@ int render_multi_impl(const dray_camera* cam, const dray_sphere* spheres, size_t
         devs.push_back(d);
     }
     for (size_t k = 0; k < n; ++k)
-        if (spheres[k].kind > DRAY_MAT_DIELECTRIC) return DRAY_ERR_UNSUPPORTED;
+        if (spheres[k].kind > DRAY_MAT_TRANSPARENT) return DRAY_ERR_UNSUPPORTED;
     dray_camera_derived dv;
     int rc = dray_camera_initialize(cam, &dv);
     if (rc) return rc;

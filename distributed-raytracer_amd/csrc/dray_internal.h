@@ -70,6 +70,7 @@ struct SceneDev {
     double* geom64 = nullptr; // n x 4: cx, cy, cz, radius
     double* mat64 = nullptr;  // n x 4: albedo rgb, fuzz or ior
     uint32_t* kind = nullptr; // n
+    uint32_t* kind32 = nullptr; // n: the kinds as the throughput kernel takes them (see scene_create_impl)
     // f32 tables (throughput and f32-plain kernels)
     float* geom32 = nullptr; // n x 4: cx, cy, cz, radius
     float* mat32 = nullptr;  // n x 4

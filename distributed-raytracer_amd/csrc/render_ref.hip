@@ -112,10 +112,16 @@ template <typename T> __device__ __forceinline__ T reflectance(T cosine, T ri) {
     return r0 + ((T)1. - r0) * x5;
 }
 
-// material.rs scatter of the four material kinds.  Returns false when the ray is absorbed.
+// material.rs scatter of the five material kinds.  Returns false when the ray is absorbed.  `so` comes in as the
+// incoming ray's origin and goes out as the scattered ray's: the hit point, except for Transparent.
 template <typename T>
 __device__ __forceinline__ bool scatter(uint32_t kind, const T* __restrict__ mat, V3<T> rd, const Hit<T>& rec,
-                                        const Stream& st, V3<T>& sd) {
+                                        const Stream& st, V3<T>& so, V3<T>& sd) {
+    if (kind == DRAY_MAT_TRANSPARENT) { // material.rs:25-31: the incoming ray, unchanged
+        sd = rd;
+        return true;
+    }
+    so = rec.p;
     if (kind == DRAY_MAT_LAMBERTIAN) { // material.rs:46-56
         V3<T> dir = vadd(rec.normal, random_unit_vector<T>(st));
         const T s = (T)1e-8; // vec3.rs:42-45
@@ -210,17 +216,18 @@ __global__ __launch_bounds__(256) void render_ref_kernel(CamDev<T> cam, const T*
                 my_segments++;
                 if (list_hit<T>(geom, n, ro, rd, rec)) { // camera.rs:270
                     st.stage = (uint32_t)(cam.max_depth - depth + 1);
-                    V3<T> sd;
-                    if (scatter<T>(kind[rec.index], mat + 4 * rec.index, rd, rec, st, sd)) {
+                    V3<T> so = ro, sd;
+                    if (scatter<T>(kind[rec.index], mat + 4 * rec.index, rd, rec, st, so, sd)) {
                         const uint32_t k = kind[rec.index];
+                        const bool white = k == DRAY_MAT_DIELECTRIC || k == DRAY_MAT_TRANSPARENT; // attenuation (1, 1, 1)
                         if (iterative) {
-                            V3<T> a = k == DRAY_MAT_DIELECTRIC ? V3<T>{(T)1., (T)1., (T)1.}
-                                                               : V3<T>{mat[4 * rec.index], mat[4 * rec.index + 1], mat[4 * rec.index + 2]};
+                            V3<T> a = white ? V3<T>{(T)1., (T)1., (T)1.}
+                                            : V3<T>{mat[4 * rec.index], mat[4 * rec.index + 1], mat[4 * rec.index + 2]};
                             att = vmul(att, a); // camera.rs:130
-                        } else if (k != DRAY_MAT_DIELECTRIC) {
-                            stack[sp++] = (uint32_t)rec.index; // a product with (1,1,1) is exact, so glass is skipped
+                        } else if (!white) {
+                            stack[sp++] = (uint32_t)rec.index; // a product with (1,1,1) is exact, so those are skipped
                         }
-                        ro = rec.p;
+                        ro = so;
                         rd = sd;
                         depth -= 1;
                         continue;
@@ -308,14 +315,14 @@ __global__ __launch_bounds__(256) void path_step_kernel(const double* __restrict
             if (list_hit<double>(geom, n_spheres, ro, rd, rec)) { // camera.rs:126
                 const Stream st = {key.k0, key.k1, (uint32_t)e.px.pixel_j * (uint32_t)W + (uint32_t)e.px.pixel_i,
                                    key.sample_offset + (uint32_t)e.px.pixel_sample_num, e.stage};
-                V3<double> sd;
+                V3<double> so = ro, sd;
                 const uint32_t mk = kind[rec.index];
-                if (scatter<double>(mk, mat + 4 * rec.index, rd, rec, st, sd)) { // camera.rs:129-133
-                    const V3<double> al = mk == DRAY_MAT_DIELECTRIC
+                if (scatter<double>(mk, mat + 4 * rec.index, rd, rec, st, so, sd)) { // camera.rs:129-133
+                    const V3<double> al = (mk == DRAY_MAT_DIELECTRIC || mk == DRAY_MAT_TRANSPARENT)
                                               ? V3<double>{1., 1., 1.}
                                               : V3<double>{mat[4 * rec.index], mat[4 * rec.index + 1], mat[4 * rec.index + 2]};
                     att = vmul(att, al);
-                    e.origin[0] = rec.p.x; e.origin[1] = rec.p.y; e.origin[2] = rec.p.z;
+                    e.origin[0] = so.x; e.origin[1] = so.y; e.origin[2] = so.z;
                     e.direction[0] = sd.x; e.direction[1] = sd.y; e.direction[2] = sd.z;
                     e.depth -= 1;
                     e.stage += 1u;

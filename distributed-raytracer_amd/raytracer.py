@@ -13,7 +13,7 @@ import ctypes as C
 import numpy as np
 
 from . import _ffi
-from ._ffi import (FLAG_COMPACT_ROWS, FLAG_ITERATIVE_PRODUCT, MAT_DEFAULT, MAT_DIELECTRIC, MAT_LAMBERTIAN, MAT_METAL,
+from ._ffi import (FLAG_COMPACT_ROWS, FLAG_ITERATIVE_PRODUCT, MAT_DEFAULT, MAT_DIELECTRIC, MAT_LAMBERTIAN, MAT_METAL, MAT_TRANSPARENT,
                    MODE_F32, MODE_F32_PLAIN, MODE_F64, DrayError)
 
 
@@ -34,6 +34,11 @@ class Material:
 
 class DefaultMaterial(Material):
     """Absorbs every ray (material.rs:10-19)."""
+
+
+class Transparent(Material):
+    """Scatters the incoming ray unchanged with attenuation (1, 1, 1) (material.rs:22-31)."""
+    kind = MAT_TRANSPARENT
 
 
 class Lambertian(Material):

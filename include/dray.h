@@ -71,7 +71,8 @@ typedef struct dray_camera_derived {
 } dray_camera_derived;
 
 /* Material kinds: material.rs:10-19 (absorbs everything), :33-57, :59-81, :83-123. */
-enum { DRAY_MAT_DEFAULT = 0, DRAY_MAT_LAMBERTIAN = 1, DRAY_MAT_METAL = 2, DRAY_MAT_DIELECTRIC = 3 };
+enum { DRAY_MAT_DEFAULT = 0, DRAY_MAT_LAMBERTIAN = 1, DRAY_MAT_METAL = 2, DRAY_MAT_DIELECTRIC = 3,
+       DRAY_MAT_TRANSPARENT = 4 /* material.rs:22-31: hands the incoming ray back unchanged, attenuation (1,1,1) */ };
 
 /* One Sphere (sphere.rs:6-10) with its material flattened in.  radius is used as
  * max(radius, 0) (sphere.rs:14); a metal's fuzz as min(fuzz, 1) (material.rs:67).

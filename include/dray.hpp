@@ -5,6 +5,7 @@
 //   Vec3 / Point3 / Color3            vec3.rs:5-23 (three f64, constructor order x, y, z)
 //   Lambertian / Metal / Dialectric   material.rs:39, :66-70 (fuzz clamped to 1), :89 (spelling as in the reference)
 //   DefaultMaterial                   material.rs:10-19 (absorbs every ray)
+//   Transparent                       material.rs:22-31 (hands the incoming ray back)
 //   Sphere::new                       sphere.rs:13-19 (radius clamped at 0)
 //   HittableList new/add/clear/len    hittable_list.rs:11-40 (insertion order is the tie-break order, :65-70)
 //   Camera: ten public fields, new()  camera.rs:41-54, :147-163
@@ -53,6 +54,12 @@ class Material {
 class DefaultMaterial : public Material {
   public:
     void flatten(dray_sphere& out) const override { out.kind = DRAY_MAT_DEFAULT; }
+};
+
+// material.rs:22-31: scatters the incoming ray unchanged with attenuation (1, 1, 1)
+class Transparent : public Material {
+  public:
+    void flatten(dray_sphere& out) const override { out.kind = DRAY_MAT_TRANSPARENT; }
 };
 
 class Lambertian : public Material {

@@ -289,6 +289,20 @@ int orc_scatter(const orc_sphere* s, const double* rd, const orc_hit* rec, orc_r
     }
 }
 
+/* Material::scatter as the path loops call it, with the incoming ray's origin at hand: Transparent
+ * (material.rs:22-31) hands the incoming ray back unchanged -- origin included -- with attenuation (1, 1, 1); every
+ * other material scatters from the hit point (orc_scatter). */
+static int scatter_from(const orc_sphere* s, const double* ro, const double* rd, const orc_hit* rec, orc_rng* rng,
+                        double* att, double* so, double* sd) {
+    if (s->kind == ORC_MAT_TRANSPARENT) {
+        att[0] = 1.0; att[1] = 1.0; att[2] = 1.0;
+        so[0] = ro[0]; so[1] = ro[1]; so[2] = ro[2];
+        sd[0] = rd[0]; sd[1] = rd[1]; sd[2] = rd[2];
+        return 1;
+    }
+    return orc_scatter(s, rd, rec, rng, att, so, sd);
+}
+
 /* --------------------------------------------------------------- Camera -- */
 
 void orc_camera_default(orc_camera* cam) { /* camera.rs:147-163 */
@@ -397,7 +411,7 @@ static void ray_color_rec(const orc_sphere* s, size_t n, const double* ro, const
     if (orc_list_hit(s, n, ro, rd, 0.001, INFINITY, &rec)) {
         double att[3], so[3], sd[3];
         rng->stage = stage;
-        if (orc_scatter(&s[rec.index], rd, &rec, rng, att, so, sd)) {
+        if (scatter_from(&s[rec.index], ro, rd, &rec, rng, att, so, sd)) {
             double inner[3];
             ray_color_rec(s, n, so, sd, depth - 1, stage + 1u, rng, inner, segments);
             orc_v_mul(att, inner, color);
@@ -429,7 +443,7 @@ void orc_ray_color_iterative(const orc_sphere* s, size_t n, const double* ro_in,
         if (orc_list_hit(s, n, ro, rd, 0.001, INFINITY, &rec)) {
             double a2[3], so[3], sd[3];
             rng->stage = stage;
-            if (orc_scatter(&s[rec.index], rd, &rec, rng, a2, so, sd)) {
+            if (scatter_from(&s[rec.index], ro, rd, &rec, rng, a2, so, sd)) {
                 orc_v_mul(att, a2, att);
                 memcpy(ro, so, sizeof ro);
                 memcpy(rd, sd, sizeof rd);
@@ -468,7 +482,7 @@ void orc_ray_color_iteration(orc_path_entry* e, const orc_sphere* s, size_t n, u
         rng.sample = sample_offset + (uint32_t)e->pixel_sample_num;
         rng.stage = e->stage;
         double a2[3], so[3], sd[3];
-        if (orc_scatter(&s[rec.index], e->direction, &rec, &rng, a2, so, sd)) { /* camera.rs:129-133 */
+        if (scatter_from(&s[rec.index], e->origin, e->direction, &rec, &rng, a2, so, sd)) { /* camera.rs:129-133 */
             orc_v_mul(e->attenuation, a2, e->attenuation);
             memcpy(e->origin, so, sizeof so);
             memcpy(e->direction, sd, sizeof sd);

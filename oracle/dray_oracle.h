@@ -59,7 +59,7 @@ typedef struct orc_camera_derived {
     double viewport_height, viewport_width, defocus_radius; /* locals of initialize, exposed for tests */
 } orc_camera_derived;
 
-enum { ORC_MAT_DEFAULT = 0, ORC_MAT_LAMBERTIAN = 1, ORC_MAT_METAL = 2, ORC_MAT_DIELECTRIC = 3 };
+enum { ORC_MAT_DEFAULT = 0, ORC_MAT_LAMBERTIAN = 1, ORC_MAT_METAL = 2, ORC_MAT_DIELECTRIC = 3, ORC_MAT_TRANSPARENT = 4 };
 
 /* One sphere with its material flattened in (src/raytracer/sphere.rs:6-10,
  * src/raytracer/material.rs:33-36,59-63,83-86). */

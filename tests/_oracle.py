@@ -104,7 +104,7 @@ PATH_ENTRY_DTYPE = np.dtype(
      ("hit_object_or_stop", "<u4"), ("_pad", "<u4")])
 assert PATH_ENTRY_DTYPE.itemsize == 128
 
-MAT_DEFAULT, MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC = 0, 1, 2, 3
+MAT_DEFAULT, MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC, MAT_TRANSPARENT = 0, 1, 2, 3, 4
 
 _lib = None
 

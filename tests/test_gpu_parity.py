@@ -538,6 +538,7 @@ def test_cpp_mirror_matches_python_binding(dray, gpu, oracle, tmp_path):
     world.add(dray.Sphere((-1.0, 0.0, -1.0), 0.5, dray.Dialectric(1.5)))
     world.add(dray.Sphere((1.0, 0.0, -1.0), 0.5, dray.Metal((0.8, 0.6, 0.2), 3.0)))
     world.add(dray.Sphere((0.0, 1.2, -1.5), -2.0, dray.DefaultMaterial()))
+    world.add(dray.Sphere((0.6, -0.3, -0.7), 0.15, dray.Transparent()))
     cam = dray.Camera.new()
     cam.aspect_ratio, cam.image_width, cam.samples_per_pixel, cam.max_depth = 16.0 / 9.0, 48, 4, 10
     cam.mode, cam.seed = dray.MODE_F64, 21
@@ -547,7 +548,7 @@ def test_cpp_mirror_matches_python_binding(dray, gpu, oracle, tmp_path):
     cam.render(world, None, color, raw, None)
     H = cam.image_height
     w, h, px = read_ppm(ppm)
-    assert (w, h) == (W, H) == (info["width"], info["height"]) and info["spheres"] == 5
+    assert (w, h) == (W, H) == (info["width"], info["height"]) and info["spheres"] == 6
     assert (px == channels(color[:W * H].reshape(H, W)).astype(np.uint8)).all()
     assert (np.fromfile(rawf, dtype=np.float64).reshape(H, W, 3) == raw[:W * H].reshape(H, W, 3)).all()
     assert info["segments"] == cam.last_stats.segments
@@ -691,6 +692,50 @@ def test_f32_image_is_independent_of_scheduling_on_random_scenes(dray, gpu):
             assert (gpu.color_to_numpy(color) == ref[0]).all() and (raw.cpu().numpy() == ref[1]).all(), (k, what)
             assert a.segments + b.segments == whole.segments
         scene.close()
+
+
+def test_transparent_material(dray, gpu, oracle):
+    """Spheres with the reference's fifth material, Transparent (material.rs:22-31), among the others: the f64 kernel
+    equals the oracle bit for bit in both product orders (segments included: a path that meets one walks through
+    all the depth it has left), the path-step entries equal the oracle's byte for byte, and the f32 kernel, which
+    renders such a sphere as the absorber it amounts to, gives the same image to the usual tolerance."""
+    spheres = dray.scene_final(1).copy()
+    rng = np.random.default_rng(4)
+    pick = rng.choice(np.arange(1, len(spheres)), 60, replace=False)
+    spheres["kind"][pick] = dray._ffi.MAT_TRANSPARENT
+    spheres["kind"][len(spheres) - 3] = dray._ffi.MAT_TRANSPARENT   # the large glass sphere in the middle
+    cam = dray.camera_final(width=96, spp=6, depth=12)
+    cam.seed = 8
+    for iterative in (0, 1):
+        cam.mode, cam.flags = dray.MODE_F64, dray.FLAG_ITERATIVE_PRODUCT if iterative else 0
+        col, raw, cnt, st = render_gpu(dray, gpu, spheres, cam)
+        ocol, oraw, ocnt, ost = oracle.render(ocam_from(oracle, cam), spheres, seed=8, iterative=iterative, threads=8)
+        assert st.segments == ost.segments and (raw == oraw).all() and (col == ocol).all()
+    cam.mode, cam.flags = dray.MODE_F32, 0
+    col32, raw32, _, st32 = render_gpu(dray, gpu, spheres, cam)
+    d = lsb_diff(col32, ocol).max(axis=-1)
+    report("transparent_f32_vs_oracle", within_1_lsb=float((d <= 1).mean()), segments_f32=int(st32.segments), segments_f64=int(ost.segments))
+    assert (d <= 1).mean() >= 0.97
+    assert st32.segments < ost.segments   # one segment per absorbed sample instead of the depth left
+    # the pixels wholly on a transparent sphere are black, and the same ones in both modes
+    H, W = cam.image_height, cam.image_width
+    black64, black32 = channels(ocol).sum(axis=-1) == 0, channels(col32).sum(axis=-1) == 0
+    assert black64.sum() > 100 and (black64 == black32).mean() > 0.999
+    # path state
+    cam.mode = dray.MODE_F64
+    px = np.stack([rng.integers(0, W, 400), rng.integers(0, H, 400), rng.integers(0, 6, 400)], axis=1).astype(np.int32)
+    e = gpu.camera_rays(cam, px)
+    oe = oracle.camera_ray_entries(ocam_from(oracle, cam), px, seed=8)
+    scene = gpu.DeviceScene(spheres, 0)
+    for step in range(14):
+        gpu.ray_color_iteration(e, scene, cam)
+        oracle.ray_color_iteration(oe, spheres, W, seed=8)
+        assert e.tobytes() == oe.tobytes(), step
+    scene.close()
+    # the mirror class flattens to the same kind
+    w = dray.HittableList()
+    w.add(dray.Sphere((0.0, 0.0, -1.0), 0.5, dray.Transparent()))
+    assert dray.flatten_world(w)["kind"][0] == dray._ffi.MAT_TRANSPARENT
 
 
 def test_render_over_several_devices_equals_one(dray, gpu):

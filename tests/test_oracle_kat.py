@@ -363,3 +363,31 @@ def test_ray_color_iteration_steps_equal_the_whole_path(oracle):
     z["depth"] = 0
     oracle.ray_color_iteration(z, spheres, W, seed=5)
     assert z["finished"][0] == 1 and z["hit_object_or_stop"][0] == 1 and (z["color"][0] == 0).all()
+
+
+def test_transparent_hands_the_ray_back(oracle):
+    """Transparent::scatter (material.rs:22-31): attenuation (1, 1, 1), scattered = the incoming ray, origin included.
+    A path that meets a Transparent sphere therefore meets it again at every depth it has left and ends black
+    (camera.rs:265-267); ray_color_iteration shows the steps: same ray, one depth less, attenuation unchanged."""
+    spheres = oracle.scene_three_spheres()
+    spheres["kind"][1] = 4            # the centre sphere, straight ahead of the camera
+    cam = oracle.camera_three_spheres(width=16, spp=1, depth=6)
+    H, W = oracle.image_height(cam), cam.image_width
+    px = np.array([(W // 2, H // 2, 0)], dtype=np.int32)
+    e = oracle.camera_ray_entries(cam, px, seed=3)
+    o0, d0 = e["origin"][0].copy(), e["direction"][0].copy()
+    for step in range(6):
+        oracle.ray_color_iteration(e, spheres, W, seed=3)
+        assert e["finished"][0] == 0 and e["hit_object_or_stop"][0] == 1
+        assert (e["origin"][0] == o0).all() and (e["direction"][0] == d0).all()
+        assert e["depth"][0] == 5 - step and e["stage"][0] == 2 + step and (e["attenuation"][0] == 1.0).all()
+    oracle.ray_color_iteration(e, spheres, W, seed=3)   # no depth left: black
+    assert e["finished"][0] == 1 and (e["color"][0] == 0.0).all()
+    # whole renders: the pixels of that sphere are black in both product orders, and each of their samples costs
+    # max_depth segments
+    solid = oracle.scene_three_spheres()
+    for iterative in (0, 1):
+        col, raw, _, st = oracle.render(cam, spheres, seed=3, iterative=iterative)
+        assert (raw[H // 2, W // 2] == 0.0).all() and (col[H // 2, W // 2] & 0xFFFFFF) == 0
+        _, raw2, _, st2 = oracle.render(cam, solid, seed=3, iterative=iterative)
+        assert raw2[H // 2, W // 2].sum() > 0 and st.segments != st2.segments
