@@ -863,7 +863,8 @@ F32Plan plan_render_f32(const CamDev<float>& cam, const Partition& part, int32_t
     const size_t table_bytes = (size_t)scene.n_narrow_padded * 8u; // cx, cy per sphere
     const bool hybrid_fits = table_bytes <= kHybridLdsLimit;
     if (variant == DRAY_SCAN_AUTO) // a grid walk pays once a ray would otherwise test a few dozen spheres
-        plan.scan = scene.n_narrow >= 64 ? DRAY_SCAN_GRID : (hybrid_fits ? DRAY_SCAN_HYBRID : DRAY_SCAN_SCALAR);
+        // (recipe scenes at 100 spp, hybrid / grid: 8 spheres 3.8 / 4.4 ms, 20: 4.0 / 4.2, 40: 4.7-5.5 / 4.6, 66: 6.1 / 5.0)
+        plan.scan = scene.n_narrow >= 40 ? DRAY_SCAN_GRID : (hybrid_fits ? DRAY_SCAN_HYBRID : DRAY_SCAN_SCALAR);
     else if (variant == DRAY_SCAN_HYBRID)
         plan.scan = hybrid_fits ? DRAY_SCAN_HYBRID : DRAY_SCAN_SCALAR;
     else

@@ -105,7 +105,7 @@ enum {
 
 /* Sphere-scan formulations of the f32 kernel; all give identical images. */
 enum {
-    DRAY_SCAN_AUTO = 0,   /* grid for scenes of 64 spheres or more, else hybrid */
+    DRAY_SCAN_AUTO = 0,   /* grid for scenes of 40 spheres or more, else hybrid */
     DRAY_SCAN_SCALAR = 1, /* exact test on every sphere, geometry through scalar loads */
     DRAY_SCAN_HYBRID = 2, /* expanded-form filter (geometry from LDS + scalar loads) in front of the exact test;
                              DRAY_ERR_UNSUPPORTED when the sphere table does not fit in LDS (> 8192 spheres) */
