@@ -311,3 +311,30 @@ def test_entry_points_reject_bad_arguments(dray):
     assert L.dray_write_ppm(b"/tmp/x.ppm", color.ctypes.data, 0, 10, 0) == INV
     L.dray_opts_default(None)
     L.dray_camera_default(None)
+
+
+def test_public_headers_compile_as_c_and_cpp(tmp_path):
+    """include/dray.h is what a foreign-function binding reads: it must be plain C (C99, pedantic) as well as C++, and a
+    C program must be able to call through it; include/dray.hpp needs nothing newer than C++14."""
+    import subprocess
+    inc = os.path.join(ROOT, "include")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-fsyntax-only", "-x", "c",
+                    os.path.join(inc, "dray.h")], check=True)
+    subprocess.run(["g++", "-std=c++14", "-Wall", "-Wextra", "-fsyntax-only", "-x", "c++", "-include",
+                    os.path.join(inc, "dray.hpp"), "/dev/null"], check=True)
+    src = tmp_path / "abi.c"
+    src.write_text('#include <stdio.h>\n#include "dray.h"\n'
+                   "int main(void) {\n"
+                   "    dray_camera cam; dray_camera_derived d; dray_opts o; dray_sphere s[4];\n"
+                   "    dray_camera_default(&cam); dray_opts_default(&o);\n"
+                   "    cam.aspect_ratio = 16.0 / 9.0; cam.image_width = 400;\n"
+                   "    if (dray_camera_initialize(&cam, &d) != DRAY_OK || d.image_height != 225) return 1;\n"
+                   "    if (dray_scene_three_spheres(s, 4) != 4 || s[2].kind != DRAY_MAT_DIELECTRIC) return 2;\n"
+                   '    printf("%s %d\\n", dray_version(), (int)sizeof(dray_path_entry));\n'
+                   "    return 0;\n}\n")
+    exe = tmp_path / "abi"
+    lib = os.path.join(ROOT, "distributed-raytracer_amd")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-I", inc, str(src), "-o", str(exe), "-L", lib,
+                    "-ldray_hip", "-Wl,-rpath," + lib, "-Wl,-rpath-link,/opt/rocm/lib"], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
+    assert out[0].startswith("dray-hip") and out[-1] == "128"
