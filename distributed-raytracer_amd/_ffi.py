@@ -22,11 +22,14 @@ ERR_UNSUPPORTED = -3
 ERR_NO_DEVICE = -4
 ERR_HIP = -5
 ERR_INTERNAL = -6
+ERR_TOO_LARGE = -7
+NOALLOC_MAX_PIXELS = 1048576
 
 MAT_DEFAULT, MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC, MAT_TRANSPARENT = 0, 1, 2, 3, 4
 MODE_F64, MODE_F32, MODE_F32_PLAIN = 0, 1, 2
 FLAG_ITERATIVE_PRODUCT = 1
 FLAG_COMPACT_ROWS = 2
+FLAG_NO_REFILL = 4
 SCAN_AUTO, SCAN_SCALAR, SCAN_HYBRID, SCAN_GRID = 0, 1, 2, 3
 
 
@@ -130,6 +133,7 @@ EXPORTS = (
     "dray_camera_initialize", "dray_render", "dray_render_multi", "dray_scene_create", "dray_scene_destroy", "dray_render_device",
     "dray_scene_final", "dray_scene_recipe", "dray_scene_three_spheres", "dray_write_ppm", "dray_camera_rays",
     "dray_path_step", "dray_camera_rays_device", "dray_path_step_device", "dray_grid_inspect",
+    "dray_render_device_noalloc",
 )
 
 _lib = None
@@ -178,6 +182,7 @@ def lib():
     L.dray_scene_destroy.argtypes = [C.c_void_p]
     L.dray_render_device.argtypes = [P(CameraPOD), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, P(Opts),
                                      C.c_void_p, P(Stats)]
+    L.dray_render_device_noalloc.argtypes = L.dray_render_device.argtypes
     L.dray_scene_final.argtypes = [C.c_uint64, C.c_void_p, C.c_size_t]
     L.dray_scene_three_spheres.argtypes = [C.c_void_p, C.c_size_t]
     L.dray_write_ppm.argtypes = [C.c_char_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32]

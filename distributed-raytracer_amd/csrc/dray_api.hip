@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <thread>
@@ -27,7 +28,23 @@ struct dray_scene {
     unsigned long long* d_accum = nullptr; // fixed-point colour sums of the f32 kernel
     size_t accum_capacity = 0;             // in u64 words
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    // The counters, the sums and the events are one set per scene, so a scene serves one call at a time: host
+    // threads take `mu` for the length of a call, and a call enqueued on another stream than the one before it
+    // first makes its stream wait for that call's last event.
+    std::mutex mu;
+    hipStream_t last_stream = nullptr;
+    bool has_last = false;
 };
+
+// Workspace of the allocation-free entry point (dray_render_device_noalloc): the f32 kernel's fixed-point sums
+// and the counters of one render, in device memory that belongs to the code object -- no hipMalloc on any call.
+// Every GPU the library runs on holds its own copy of the array (25 MiB) until the process ends.  In host code
+// the array's name is only a handle for hipGetSymbolAddress: kernels and memsets are given the per-device
+// address that call returns (noalloc_workspace below), never the name.
+constexpr size_t kNoAllocMaxPixels = DRAY_NOALLOC_MAX_PIXELS;
+constexpr size_t kNoAllocCounterWords = 32;                              // 256 B: the DeviceCounters, padded
+constexpr size_t kNoAllocWords = kNoAllocCounterWords + 3 * kNoAllocMaxPixels; // counters, then three sum planes
+static __device__ __align__(256) unsigned long long scratch[kNoAllocWords];
 
 namespace {
 
@@ -509,8 +526,34 @@ int scene_create_impl(const dray_sphere* sp, size_t n, int32_t device, dray_scen
     return DRAY_OK;
 }
 
+// Per-device address of `scratch`, looked up on the first allocation-free call on that device.
+constexpr int kMaxDevices = 64;
+std::mutex g_noalloc_mu;
+unsigned long long* g_noalloc_ptr[kMaxDevices] = {};
+
+// `device` must be current.  Returns the device's copy of the workspace array, or null with g_detail set.
+unsigned long long* noalloc_workspace(int device) {
+    if (device < 0 || device >= kMaxDevices) {
+        snprintf(g_detail, sizeof g_detail, "device %d is beyond the %d the allocation-free workspace table holds", device,
+                 kMaxDevices);
+        return nullptr;
+    }
+    std::lock_guard<std::mutex> lock(g_noalloc_mu);
+    if (!g_noalloc_ptr[device]) {
+        void* p = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !p) {
+            (void)hip_fail(e, "hipGetSymbolAddress(scratch)");
+            return nullptr;
+        }
+        g_noalloc_ptr[device] = (unsigned long long*)p;
+    }
+    return g_noalloc_ptr[device];
+}
+
 int render_device_impl(const dray_camera* cam, dray_scene* scene, uint32_t* d_color, double* d_raw, int32_t* d_count,
-                       size_t buf_len, const dray_opts* opts_in, void* stream_v, dray_stats* stats) {
+                       size_t buf_len, const dray_opts* opts_in, void* stream_v, dray_stats* stats,
+                       bool noalloc = false) {
     const auto t_begin = std::chrono::steady_clock::now();
     if (!camera_ok(cam) || !scene || !d_color) return DRAY_ERR_INVALID_ARG;
     dray_opts opts;
@@ -549,41 +592,68 @@ int render_device_impl(const dray_camera* cam, dray_scene* scene, uint32_t* d_co
     hipStream_t stream = (hipStream_t)stream_v;
     const RngKey key = {(uint32_t)opts.seed, (uint32_t)(opts.seed >> 32), opts.sample_offset};
 
-    HIP_TRY(hipMemsetAsync(scene->d_counters, 0, sizeof(DeviceCounters), stream));
+    // one call at a time per scene (see dray_scene)
+    std::lock_guard<std::mutex> lock(scene->mu);
+    if (scene->has_last && scene->last_stream != stream) HIP_TRY(hipStreamWaitEvent(stream, scene->ev[2], 0));
+    scene->last_stream = stream;
+
+    // the counters and the f32 kernel's sums: the scene's own buffers (grown when a frame needs more), or the
+    // library's static array for the entry point that may not allocate
+    DeviceCounters* d_counters = scene->d_counters;
+    unsigned long long* d_accum = nullptr;
+    if (noalloc) {
+        if ((size_t)part.n_rows * (size_t)W > kNoAllocMaxPixels) {
+            snprintf(g_detail, sizeof g_detail, "%d rows x %d pixels exceed the %zu pixels of the allocation-free workspace",
+                     part.n_rows, W, kNoAllocMaxPixels);
+            return DRAY_ERR_TOO_LARGE;
+        }
+        unsigned long long* ws = noalloc_workspace(scene->device);
+        if (!ws) return DRAY_ERR_HIP;
+        d_counters = (DeviceCounters*)ws;
+        d_accum = ws + kNoAllocCounterWords;
+    }
+    static_assert(sizeof(DeviceCounters) <= kNoAllocCounterWords * sizeof(unsigned long long), "counters outgrew their slot");
+
+    HIP_TRY(hipMemsetAsync(d_counters, 0, sizeof(DeviceCounters), stream));
     if (opts.mode == DRAY_MODE_F32) {
         const CamDev<float> c = make_cam<float>(*cam, dv);
-        const F32Plan plan = plan_render_f32(c, part, opts.pixels_per_pool, opts.variant, scene->dev, scene->device);
+        F32Plan plan = plan_render_f32(c, part, opts.pixels_per_pool, opts.variant, scene->dev, scene->device);
+        plan.no_refill = (opts.flags & DRAY_FLAG_NO_REFILL) ? 1 : 0;
         if (opts.variant == DRAY_SCAN_HYBRID && plan.scan != DRAY_SCAN_HYBRID) return DRAY_ERR_UNSUPPORTED; // table beyond the LDS staging limit
-        if (plan.accum_words > scene->accum_capacity) {
-            if (scene->d_accum) HIP_TRY(hipFree(scene->d_accum));
-            scene->d_accum = nullptr;
-            scene->accum_capacity = 0;
-            HIP_TRY(hipMalloc((void**)&scene->d_accum, plan.accum_words * sizeof(unsigned long long)));
-            scene->accum_capacity = plan.accum_words;
+        if (!noalloc) {
+            if (plan.accum_words > scene->accum_capacity) {
+                if (scene->d_accum) HIP_TRY(hipFree(scene->d_accum)); // waits for the device: no earlier call still reads it
+                scene->d_accum = nullptr;
+                scene->accum_capacity = 0;
+                HIP_TRY(hipMalloc((void**)&scene->d_accum, plan.accum_words * sizeof(unsigned long long)));
+                scene->accum_capacity = plan.accum_words;
+            }
+            d_accum = scene->d_accum;
         }
-        HIP_TRY(hipMemsetAsync(scene->d_accum, 0, plan.accum_words * sizeof(unsigned long long), stream));
+        HIP_TRY(hipMemsetAsync(d_accum, 0, plan.accum_words * sizeof(unsigned long long), stream));
         HIP_TRY(hipEventRecord(scene->ev[0], stream));
         if (cam->max_depth > 0) // camera.rs:265: with no depth every sample is black and no ray is traced
-            HIP_TRY(launch_render_f32(c, scene->dev, part, key, plan, scene->d_accum, scene->d_counters, stream));
+            HIP_TRY(launch_render_f32(c, scene->dev, part, key, plan, d_accum, d_counters, stream));
         HIP_TRY(hipEventRecord(scene->ev[1], stream));
-        HIP_TRY(launch_resolve_f32(c, part, scene->d_accum, d_color, d_raw, d_count, stream));
+        HIP_TRY(launch_resolve_f32(c, part, d_accum, d_color, d_raw, d_count, stream));
         HIP_TRY(hipEventRecord(scene->ev[2], stream));
     } else {
         HIP_TRY(hipEventRecord(scene->ev[0], stream));
         if (opts.mode == DRAY_MODE_F64)
             HIP_TRY(launch_render_ref_f64(make_cam<double>(*cam, dv), scene->dev, part, key, opts.flags, d_color, d_raw,
-                                          d_count, scene->d_counters, stream));
+                                          d_count, d_counters, stream));
         else
             HIP_TRY(launch_render_ref_f32(make_cam<float>(*cam, dv), scene->dev, part, key, opts.flags, d_color, d_raw,
-                                          d_count, scene->d_counters, stream));
+                                          d_count, d_counters, stream));
         HIP_TRY(hipEventRecord(scene->ev[1], stream));
         HIP_TRY(hipEventRecord(scene->ev[2], stream));
     }
+    scene->has_last = true;
 
     if (stats) {
         HIP_TRY(hipEventSynchronize(scene->ev[2]));
         DeviceCounters hc{};
-        HIP_TRY(hipMemcpy(&hc, scene->d_counters, sizeof hc, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(&hc, d_counters, sizeof hc, hipMemcpyDeviceToHost));
         float k_ms = 0.f, r_ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&k_ms, scene->ev[0], scene->ev[1]));
         HIP_TRY(hipEventElapsedTime(&r_ms, scene->ev[1], scene->ev[2]));
@@ -835,12 +905,19 @@ int path_step_device_impl(dray_scene* scene, int32_t image_width, dray_path_entr
     if (g.err != hipSuccess) return hip_fail(g.err, "hipSetDevice");
     const RngKey key = {(uint32_t)opts.seed, (uint32_t)(opts.seed >> 32), opts.sample_offset};
     hipStream_t stream = (hipStream_t)stream_v;
-    if (count) {
+    if (count) { // only the counting form touches the scene's workspace; the plain form reads the sphere tables alone
+        std::lock_guard<std::mutex> lock(scene->mu);
+        if (scene->has_last && scene->last_stream != stream) HIP_TRY(hipStreamWaitEvent(stream, scene->ev[2], 0));
+        scene->last_stream = stream;
         HIP_TRY(hipMemsetAsync(scene->d_counters, 0, sizeof(DeviceCounters), stream));
         HIP_TRY(hipEventRecord(scene->ev[0], stream));
+        HIP_TRY(launch_path_step(scene->dev, key, image_width, d_entries, n, scene->d_counters, stream));
+        HIP_TRY(hipEventRecord(scene->ev[1], stream));
+        HIP_TRY(hipEventRecord(scene->ev[2], stream));
+        scene->has_last = true;
+        return DRAY_OK;
     }
-    HIP_TRY(launch_path_step(scene->dev, key, image_width, d_entries, n, count ? scene->d_counters : nullptr, stream));
-    if (count) HIP_TRY(hipEventRecord(scene->ev[1], stream));
+    HIP_TRY(launch_path_step(scene->dev, key, image_width, d_entries, n, nullptr, stream));
     return DRAY_OK;
 }
 
@@ -917,6 +994,7 @@ const char* dray_strerror(int status) {
     case DRAY_ERR_NO_DEVICE: return "no HIP device";
     case DRAY_ERR_HIP: return g_detail[0] ? g_detail : "HIP runtime error";
     case DRAY_ERR_INTERNAL: return "internal error";
+    case DRAY_ERR_TOO_LARGE: return g_detail[0] ? g_detail : "frame larger than the allocation-free workspace";
     default: return "unknown status";
     }
 }
@@ -1023,6 +1101,15 @@ int dray_render_device(const dray_camera* cam, dray_scene* scene, uint32_t* d_co
                        size_t buf_len, const dray_opts* opts, void* stream, dray_stats* stats) {
     try {
         return render_device_impl(cam, scene, d_color, d_raw, d_count, buf_len, opts, stream, stats);
+    } catch (...) {
+        return DRAY_ERR_INTERNAL;
+    }
+}
+
+int dray_render_device_noalloc(const dray_camera* cam, dray_scene* scene, uint32_t* d_color, double* d_raw,
+                               int32_t* d_count, size_t buf_len, const dray_opts* opts, void* stream, dray_stats* stats) {
+    try {
+        return render_device_impl(cam, scene, d_color, d_raw, d_count, buf_len, opts, stream, stats, true);
     } catch (...) {
         return DRAY_ERR_INTERNAL;
     }

@@ -90,7 +90,10 @@ struct SceneDev {
     GridDev grid{};
 };
 
-constexpr size_t kHybridLdsLimit = 64 * 1024; // largest cx,cy table (8 B per sphere) the hybrid scan stages in LDS
+// A workgroup of the f32 kernel may hold 64 KiB of LDS: its static arrays (pixel sums, tags, draw requests) plus,
+// for the hybrid scan, the staged cx,cy table (8 B per sphere).  Larger tables take another scan.
+constexpr size_t kF32StaticLds = 8 * 1024;                       // budget of the static arrays (asserted in the kernel)
+constexpr size_t kHybridLdsLimit = 64 * 1024 - kF32StaticLds;    // largest table: 7 168 narrow spheres
 
 struct DeviceCounters {
     unsigned long long segments;
@@ -120,6 +123,7 @@ struct F32Plan {
     int32_t grid, block;
     size_t lds_bytes;         // dynamic LDS of the launch
     int32_t scan;             // the DRAY_SCAN_* formulation the launch uses (never DRAY_SCAN_AUTO)
+    int32_t no_refill;        // DRAY_FLAG_NO_REFILL: idle lanes wait until their whole wave is idle
 };
 F32Plan plan_render_f32(const CamDev<float>& cam, const Partition& part, int32_t pixels_per_pool, int32_t variant,
                         const SceneDev& scene, int device);

@@ -27,6 +27,7 @@
 // ray-sphere test and keeps the SGPR-sourced ones under ~60 % of the mix (scan_hybrid below: 8 operations, 3
 // of them SGPR-sourced, against 11 and 4 for the direct form of sphere.rs:29-36).
 #include <cstdlib>
+#include <mutex>
 
 #include "dray_device.h"
 #include "dray_internal.h"
@@ -136,9 +137,10 @@ __device__ __forceinline__ F3 coop_draw(const Stream& st, const uint32_t (&w)[4]
         if (disk) v = {ok_a ? ax : bx, ok_a ? ay : by, 0.f};
         const bool ok = serving & (disk ? (ok_a | ok_b) : ok_vector);
         const unsigned long long okm = __ballot(ok);
-        const uint32_t mine = (uint32_t)(okm >> (rank << shift)) & ((1u << (1u << shift)) - 1u); // my servers' verdicts
+        const uint32_t first = pending ? (rank << shift) : 0u; // my first server lane (< 64; a lane that is not pending has none)
+        const uint32_t mine = (uint32_t)(okm >> first) & ((1u << (1u << shift)) - 1u); // my servers' verdicts
         const bool got = pending & (mine != 0u);
-        const int from = got ? (int)((rank << shift) + (uint32_t)__builtin_ctz(mine)) : lane;
+        const int from = got ? (int)(first + (uint32_t)__builtin_ctz(mine)) : lane;
         const float vx = __shfl(v.x, from, 64), vy = __shfl(v.y, from, 64), vz = __shfl(v.z, from, 64);
         if (got) {
             res = {vx, vy, vz};
@@ -409,6 +411,7 @@ struct F32Args {
     RngKey key;
     int32_t pixels_per_pool;
     int32_t grab_pixels; // pixels a wave takes from the global queue per atomic (a multiple of pixels_per_pool)
+    int32_t no_refill;   // idle lanes take new samples only once every lane of the wave is idle (compaction off)
     unsigned long long* accum;
     DeviceCounters* counters;
 };
@@ -446,6 +449,7 @@ __device__ __forceinline__ void render_f32_body() {
     __shared__ unsigned long long lds_sum[4][kSlots][3]; // [wave of the block][slot][r, g, b]
     __shared__ uint32_t lds_tag[4][kSlots];              // the slot's pixel: its Philox pixel word (j * W + i)
     __shared__ uint4 lds_req[4][64];                     // coop_draw: streams handed to server lanes
+    static_assert(sizeof(lds_sum) + sizeof(lds_tag) + sizeof(lds_req) <= kF32StaticLds, "static LDS outgrew its budget");
     const int wv = (int)(threadIdx.x >> 6);
     if (lane < kSlots) {
         __hip_atomic_store(&lds_tag[wv][lane], kNoPixel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -651,6 +655,8 @@ __device__ __forceinline__ void render_f32_body() {
         // together with the scattering lanes' first block ----------------------------------------------
         bool need = stage == 0 && !camera;
         unsigned long long want = __ballot(need);
+        // compaction switched off: the wave refills only as a whole, once its last path has ended
+        if (a->no_refill != 0 && __ballot(stage > 0) != 0ull) want = 0ull;
         while (want != 0ull) {
             const uint32_t W = (uint32_t)a->cam.W, spp = (uint32_t)a->cam.spp;
             // at least one sample per lane in a pixel and rows longer than a pool: a hand-out wraps at most once
@@ -870,14 +876,26 @@ F32Plan plan_render_f32(const CamDev<float>& cam, const Partition& part, int32_t
     else
         plan.scan = variant;
     plan.lds_bytes = plan.scan == DRAY_SCAN_HYBRID ? table_bytes : 0u;
-    int cus = 256, per_cu = 4;
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
-    int occ = 0;
-    const hipError_t oe = plan.scan == DRAY_SCAN_HYBRID ? occupancy_of<kScanHybrid>(&occ, plan.block, plan.lds_bytes)
-                          : plan.scan == DRAY_SCAN_GRID ? occupancy_of<kScanGrid>(&occ, plan.block, 0)
-                                                        : occupancy_of<kScanScalar>(&occ, plan.block, 0);
-    if (oe == hipSuccess && occ > 0) per_cu = occ;
+    // compute units of the device and resident blocks per unit of the two kernels without dynamic LDS: asked once per device
+    struct DeviceFacts { int cus = 0, occ_scalar = 0, occ_grid = 0; };
+    static DeviceFacts facts[64];
+    static std::mutex facts_mu;
+    int cus = 256, per_cu = 4, occ = 0;
+    {
+        std::lock_guard<std::mutex> lock(facts_mu);
+        DeviceFacts local;
+        DeviceFacts& f = (device >= 0 && device < 64) ? facts[device] : local;
+        if (f.cus == 0) {
+            int v = 0;
+            f.cus = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && v > 0) ? v : 256;
+            if (occupancy_of<kScanScalar>(&v, plan.block, 0) == hipSuccess && v > 0) f.occ_scalar = v;
+            if (occupancy_of<kScanGrid>(&v, plan.block, 0) == hipSuccess && v > 0) f.occ_grid = v;
+        }
+        cus = f.cus;
+        occ = plan.scan == DRAY_SCAN_GRID ? f.occ_grid : plan.scan == DRAY_SCAN_SCALAR ? f.occ_scalar : 0;
+    }
+    if (plan.scan == DRAY_SCAN_HYBRID && occupancy_of<kScanHybrid>(&occ, plan.block, plan.lds_bytes) != hipSuccess) occ = 0;
+    if (occ > 0) per_cu = occ;
     plan.grid = cus * per_cu;
     const long long npix = (long long)part.n_rows * cam.W;
     const int32_t spp = cam.spp > 0 ? cam.spp : 1;
@@ -932,6 +950,7 @@ hipError_t launch_render_f32(const CamDev<float>& cam, const SceneDev& scene, co
     for (int q = 0; q < 4; ++q) args.bound[q] = t.bound[q];
     args.grid = scene.grid;
     args.part = part; args.key = key; args.pixels_per_pool = plan.pixels_per_pool; args.grab_pixels = plan.grab_pixels;
+    args.no_refill = plan.no_refill;
     args.accum = d_accum; args.counters = d_counters;
     auto launch = [&](auto kernel) {
         hipLaunchKernelGGL(kernel, dim3(plan.grid), dim3(plan.block), plan.lds_bytes, stream, args);

@@ -68,9 +68,10 @@ def alloc_buffers(cam: Camera, device, rows=None, with_raw=True):
 
 
 def render_device(cam: Camera, scene: DeviceScene, color, raw=None, count=None, stream=None, want_stats=True,
-                  **opt_overrides):
+                  noalloc=False, **opt_overrides):
     """Camera::render with device buffers.  Returns dray_stats (or None when want_stats is False: then the
-    call only enqueues work on ``stream``)."""
+    call only enqueues work on ``stream``).  ``noalloc`` takes the entry point that never allocates device memory
+    (dray_render_device_noalloc: the library's static workspace, frames of at most NOALLOC_MAX_PIXELS pixels)."""
     import torch
     pc, nc = _ptr(color, torch.int32, "color")
     pr, nr = _ptr(raw, torch.float64, "raw")
@@ -88,8 +89,9 @@ def render_device(cam: Camera, scene: DeviceScene, color, raw=None, count=None, 
     opts = cam.opts(**opt_overrides)
     opts.device = scene.device
     st = _ffi.Stats() if want_stats else None
-    rc = _ffi.lib().dray_render_device(C.byref(pod), scene.handle, pc, pr, pn, buf_len, C.byref(opts),
-                                       C.c_void_p(stream.cuda_stream), C.byref(st) if want_stats else None)
+    call = _ffi.lib().dray_render_device_noalloc if noalloc else _ffi.lib().dray_render_device
+    rc = call(C.byref(pod), scene.handle, pc, pr, pn, buf_len, C.byref(opts), C.c_void_p(stream.cuda_stream),
+              C.byref(st) if want_stats else None)
     _ffi.check(rc)
     cam.last_stats = st
     return st

@@ -101,14 +101,33 @@ class DistributedRenderer:
         self.color, self.raw, self.count = alloc(self.S, self.W)
         self.render_rows = render_rows
         self.samples_done = 0
+        self._gather_events = []
 
-    def step(self, gather=True):
-        """One pass of the camera's samples_per_pixel over this rank's rows, then the gather."""
+    def step(self, gather=True, time_gather=False):
+        """One pass of the camera's samples_per_pixel over this rank's rows, then the gather.  With ``time_gather`` the
+        gather is bracketed by two events on the current stream (read later through gather_ms, without a wait here)."""
         stats = self.render_rows(self.cam, self.row_begin, self.row_step, self.color, self.raw, self.count,
                                  self.samples_done)
         self.samples_done += self.cam.samples_per_pixel
+        timed = gather and time_gather and getattr(self.color, "is_cuda", False)
+        if timed:
+            import torch
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         image = gather_image(self.color, self.H, self.group) if gather else None
+        if timed:
+            e1.record()
+            self._gather_events.append((e0, e1))
         return image, stats
+
+    def gather_ms(self):
+        """Total device time of the gathers timed so far (all-gather + de-interleave), in ms; waits for them."""
+        total = 0.0
+        for e0, e1 in self._gather_events:
+            e1.synchronize()
+            total += e0.elapsed_time(e1)
+        self._gather_events = []
+        return total
 
     def gather_sums(self):
         """The other two buffers of the render call (camera.rs:212-213) for the whole image on every rank: the running

@@ -38,7 +38,8 @@ typedef enum dray_status {
     DRAY_ERR_UNSUPPORTED = -3,
     DRAY_ERR_NO_DEVICE = -4,
     DRAY_ERR_HIP = -5,
-    DRAY_ERR_INTERNAL = -6
+    DRAY_ERR_INTERNAL = -6,
+    DRAY_ERR_TOO_LARGE = -7 /* dray_render_device_noalloc: more pixels than DRAY_NOALLOC_MAX_PIXELS */
 } dray_status;
 
 /* The ten public camera fields, src/raytracer/camera.rs:42-53, same order. */
@@ -100,7 +101,12 @@ enum {
     DRAY_FLAG_ITERATIVE_PRODUCT = 1u,
     /* Rendered rows are stored back to back: row j goes to slab row (j-row_begin)/row_step.
      * Without it row j is stored at j*image_width as the reference does (colors.rs:37). */
-    DRAY_FLAG_COMPACT_ROWS = 2u
+    DRAY_FLAG_COMPACT_ROWS = 2u,
+    /* f32 mode: switch the wave-level compaction of terminated paths off.  By default a lane whose path has ended
+     * takes the next sample of its wave's pool at once, so all 64 lanes stay busy; with this flag it idles until
+     * every path of its wave has ended and the wave refills as a whole (64 samples in lock-step, as a kernel
+     * without compaction runs them).  The image is the same; only the time differs (an A/B switch). */
+    DRAY_FLAG_NO_REFILL = 4u
 };
 
 /* Sphere-scan formulations of the f32 kernel; all give identical images. */
@@ -108,7 +114,7 @@ enum {
     DRAY_SCAN_AUTO = 0,   /* grid for scenes of 40 spheres or more, else hybrid */
     DRAY_SCAN_SCALAR = 1, /* exact test on every sphere, geometry through scalar loads */
     DRAY_SCAN_HYBRID = 2, /* expanded-form filter (geometry from LDS + scalar loads) in front of the exact test;
-                             DRAY_ERR_UNSUPPORTED when the sphere table does not fit in LDS (> 8192 spheres) */
+                             DRAY_ERR_UNSUPPORTED when the sphere table does not fit in LDS (> 7168 spheres) */
     DRAY_SCAN_GRID = 3    /* every lane walks its ray through a uniform grid over the spheres and applies the exact
                              test to the spheres of the cells it crosses */
 };
@@ -184,9 +190,25 @@ int dray_scene_create(const dray_sphere* spheres, size_t n_spheres, int32_t devi
 void dray_scene_destroy(dray_scene* scene);
 /* Same contract as dray_render but color/raw/count are device pointers on the scene's device
  * and the work is enqueued on `stream` (a hipStream_t, NULL = default stream).  With stats == NULL
- * the call returns once the work is enqueued; with stats it waits for completion and fills them. */
+ * the call returns once the work is enqueued; with stats it waits for completion and fills them.
+ * A dray_scene owns one workspace (counters, colour sums, events), so it serves one call at a time: calls from
+ * several host threads take turns, and a call on another stream than the scene's previous call first makes its
+ * stream wait for that call to finish on the GPU.  For renders that should overlap, create one scene per stream. */
 int dray_render_device(const dray_camera* cam, dray_scene* scene, uint32_t* d_color, double* d_raw, int32_t* d_count,
                        size_t buf_len, const dray_opts* opts, void* stream, dray_stats* stats);
+
+/* dray_render_device for callers that cannot allocate device memory: code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc.  It has no counterpart in the reference.  Same arguments, same results
+ * bit for bit, but the call's workspace (the f32 kernel's fixed-point colour sums, 24 bytes per pixel, and the
+ * counters) is a static array in the library's device code instead of buffers the scene allocates and grows: the
+ * call never calls hipMalloc or hipFree.  Limits: the rows it renders times image_width may not exceed
+ * DRAY_NOALLOC_MAX_PIXELS (DRAY_ERR_TOO_LARGE otherwise); every GPU the library runs on holds its own 25 MiB copy
+ * of the array until the process ends; all such calls on one GPU share that GPU's copy, so two of them that
+ * overlap in time (different streams or host threads, the same scene or not) race -- keep them on one stream.  With
+ * stats the call blocks and copies the counters back (32 bytes); leave stats NULL under graph capture. */
+#define DRAY_NOALLOC_MAX_PIXELS 1048576
+int dray_render_device_noalloc(const dray_camera* cam, dray_scene* scene, uint32_t* d_color, double* d_raw,
+                               int32_t* d_count, size_t buf_len, const dray_opts* opts, void* stream, dray_stats* stats);
 
 /* ---- the path state the reference's distributed layer feeds on ---------------------------- */
 /* PixelIndexEntry, camera.rs:8-13. */

@@ -263,9 +263,10 @@ def test_f32_grid_scan_equals_scalar_scan_on_random_scenes(dray, gpu):
 def test_f32_close_to_oracle(dray, gpu, oracle):
     """f32 throughput kernel vs the f64 oracle on identical Philox streams.
 
-    Tolerance: >= 97 % of pixels within 1 LSB on every channel, mean |diff| < 0.1 LSB, segment count within 1 %.
-    (A path whose accept/reject or hit/miss decision flips between f32 and f64 changes a whole sample, so a
-    few pixels may move by more than 1 LSB at low sample counts.)"""
+    Tolerance: >= 99.5 % of pixels within 1 LSB on every channel (measured 99.68 %), >= 99.95 % within 4, no pixel
+    further than 32 LSB (measured 21), mean |diff| < 0.02 LSB (measured 0.0086), segment count within 0.3 %
+    (measured +0.13 %).  (A path whose accept/reject or hit/miss decision flips between f32 and f64 changes a whole
+    sample -- one of 32 here -- so a few pixels move by more than 1 LSB at low sample counts.)"""
     spheres = dray.scene_final(1)
     cam = dray.camera_final(width=192, spp=32, depth=50)
     cam.mode = dray.MODE_F32
@@ -278,9 +279,10 @@ def test_f32_close_to_oracle(dray, gpu, oracle):
           "mean", d.mean(), "segments", st.segments, ost.segments)
     report("f32_vs_oracle_final_192x108_32spp", hist=[int(x) for x in hist], max=int(worst.max()), mean=float(d.mean()),
            within_1lsb=float((worst <= 1).mean()), segments=int(st.segments), oracle_segments=int(ost.segments))
-    assert (worst <= 1).mean() >= 0.97
-    assert d.mean() < 0.1
-    assert abs(int(st.segments) - int(ost.segments)) <= 0.01 * ost.segments
+    assert (worst <= 1).mean() >= 0.995
+    assert (worst <= 4).mean() >= 0.9995 and worst.max() <= 32
+    assert d.mean() < 0.02
+    assert abs(int(st.segments) - int(ost.segments)) <= 0.003 * ost.segments
     assert st.samples == ost.samples
     # f32-plain (reference operation order in f32) obeys the same bound
     cam.mode = dray.MODE_F32_PLAIN
@@ -303,8 +305,9 @@ def test_f32_three_spheres_close_to_oracle(dray, gpu, oracle):
     d = lsb_diff(col, ocol)
     report("f32_vs_oracle_three_spheres_200x112_20spp", within_1lsb=float((d.max(-1) <= 1).mean()), max=int(d.max()),
            mean=float(d.mean()))
-    assert (d.max(-1) <= 1).mean() >= 0.97
-    assert d.mean() < 0.1
+    # measured: 99.996 % within 1 LSB, max 2, mean 6e-5
+    assert (d.max(-1) <= 1).mean() >= 0.9999 and d.max() <= 4
+    assert d.mean() < 0.001
 
 
 def test_host_buffer_render_api(dray, gpu, oracle):
@@ -415,9 +418,10 @@ def test_edge_cases(dray, gpu, oracle):
 
 
 def test_large_scene_scalar_fallback_and_hybrid(dray, gpu, oracle):
-    """A 10 001-sphere grid: f64 kernel equal to the oracle; the f32 kernel's automatic choice (the narrow
-    spheres exceed the hybrid scan's staging limit, so the scalar scan runs) equal to the forced scalar scan and
-    within the f32 bound of the oracle.  A 5 000-sphere grid still takes the hybrid scan and equals the scalar."""
+    """A 10 001-sphere grid: f64 kernel equal to the oracle; the f32 kernel's automatic choice (the grid walk) equal
+    to the forced scalar scan and within the f32 bound of the oracle; the hybrid scan, whose staged table would not
+    fit in a workgroup's LDS, is refused when forced.  A 4 900-sphere scene and one just under the staging limit
+    (7 168 narrow spheres) still take the hybrid scan and equal the scalar scan; one just over it is refused."""
     spheres = dray.scene_grid_10k(2)
     assert len(spheres) > 8192 + 4
     cam = dray.camera_final(width=64, spp=2, depth=10)
@@ -436,13 +440,24 @@ def test_large_scene_scalar_fallback_and_hybrid(dray, gpu, oracle):
     d = lsb_diff(a[0], ocol)
     report("f32_vs_oracle_grid10k_64x36_2spp", within_1lsb=float((d.max(-1) <= 1).mean()), mean=float(d.mean()),
            segments=int(a[3].segments), oracle_segments=int(ost.segments))
-    # 2 samples per pixel: one flipped decision moves a pixel a lot, so the share is looser than at 32 spp
-    assert (d.max(-1) <= 1).mean() >= 0.95
-    assert abs(int(a[3].segments) - int(ost.segments)) <= 0.01 * ost.segments
+    # 2 samples per pixel, 2 304 pixels: one flipped decision moves a pixel a lot; measured 99.96 % (one pixel)
+    assert (d.max(-1) <= 1).mean() >= 0.999
+    assert abs(int(a[3].segments) - int(ost.segments)) <= 0.002 * ost.segments
     mid = dray.scene_recipe(2, -35, 35, 0.8, 0.15, 0.5)
-    assert 4096 < len(mid) < 8192
-    a = render_gpu(dray, gpu, mid, cam, seed=18, variant=dray.SCAN_HYBRID)
-    b = render_gpu(dray, gpu, mid, cam, seed=18, variant=dray.SCAN_SCALAR)
+    assert 4096 < len(mid) < 7168
+    edge = dray.scene_recipe(2, -42, 42, 0.8, 0.15, 0.5)     # the largest table the hybrid scan stages: static + dynamic
+    assert 7168 - 128 < len(edge) - 1 <= 7168                # LDS of the workgroup just inside 64 KiB
+    for sp in (mid, edge):
+        a = render_gpu(dray, gpu, sp, cam, seed=18, variant=dray.SCAN_HYBRID)
+        b = render_gpu(dray, gpu, sp, cam, seed=18, variant=dray.SCAN_SCALAR)
+        assert (a[0] == b[0]).all() and (a[1] == b[1]).all() and a[3].segments == b[3].segments
+    over = dray.scene_recipe(2, -43, 43, 0.8, 0.15, 0.5)
+    assert 7168 < len(over) - 1 < 8192
+    with pytest.raises(dray.DrayError) as e:
+        render_gpu(dray, gpu, over, cam, seed=18, variant=dray.SCAN_HYBRID)
+    assert e.value.status == dray._ffi.ERR_UNSUPPORTED
+    a = render_gpu(dray, gpu, over, cam, seed=18, variant=dray.SCAN_AUTO)
+    b = render_gpu(dray, gpu, over, cam, seed=18, variant=dray.SCAN_SCALAR)
     assert (a[0] == b[0]).all() and (a[1] == b[1]).all() and a[3].segments == b[3].segments
 
 
@@ -469,9 +484,10 @@ def test_glass_metal_depth_100(dray, gpu, oracle):
     report("f32_vs_oracle_glass_metal_96x54_8spp_d100", within_1lsb=float((d.max(-1) <= 1).mean()),
            mean=float(d.mean()), max=int(d.max()), segments=int(st.segments), oracle_segments=int(ost.segments),
            mean_path_length=float(ost.segments) / float(ost.samples))
-    # specular chains amplify a last-bit difference at every bounce: tolerance >= 90 % of pixels within 1 LSB
-    assert (d.max(-1) <= 1).mean() >= 0.90
-    assert abs(int(st.segments) - int(ost.segments)) <= 0.02 * ost.segments
+    # specular chains amplify a last-bit difference at every bounce, and a flipped sample is one of 8: tolerance
+    # >= 99.5 % of pixels within 1 LSB (measured 99.85 %), none further than 32 LSB (measured 14), segments within 0.3 %
+    assert (d.max(-1) <= 1).mean() >= 0.995 and d.max() <= 32
+    assert abs(int(st.segments) - int(ost.segments)) <= 0.003 * ost.segments
 
 
 def test_full_hd_properties(dray, gpu, oracle):
@@ -498,8 +514,8 @@ def test_full_hd_properties(dray, gpu, oracle):
     d = lsb_diff(full[0][rows], ocol[rows])
     report("f32_vs_oracle_full_hd_rows", within_1lsb=float((d.max(-1) <= 1).mean()), mean=float(d.mean()),
            max=int(d.max()), kernel_ms=float(full[3].kernel_ms), segments=int(full[3].segments))
-    assert (d.max(-1) <= 1).mean() >= 0.99  # 100 samples per pixel: tighter than the 32-sample bound
-    assert d.mean() < 0.05
+    assert (d.max(-1) <= 1).mean() >= 0.9999 and d.max() <= 2  # 100 samples per pixel; measured 100 %, max 1
+    assert d.mean() < 0.001
     scene = gpu.DeviceScene(spheres, 0)
     color, raw2, count = gpu.alloc_buffers(cam, 0)
     segs = 0
@@ -617,8 +633,8 @@ def test_scan_variants_agree_on_random_scenes(dray, gpu):
 def test_f64_kernel_matches_oracle_on_random_scenes(dray, gpu, oracle):
     """The same generator against the CPU oracle: for 60 random scenes the f64 kernel's running sums, colours and
     segment counts equal the oracle's bit for bit (both product orders alternate), and the f32 kernel on the same
-    streams stays close: at least 90 % of the pixels within 1 LSB in every scene (2 to 4 samples per pixel: one flipped
-    sample moves a pixel by tens of LSB), 97 % over all scenes, segment totals within 2 %."""
+    streams stays close: at least 98.5 % of the pixels within 1 LSB in every scene (2 to 4 samples per pixel: one flipped
+    sample moves a pixel by tens of LSB), 99.8 % over all scenes, segment totals within 0.1 %."""
     import os
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
@@ -644,8 +660,9 @@ def test_f64_kernel_matches_oracle_on_random_scenes(dray, gpu, oracle):
             worst = (float(ok.mean()), what)
     report("random_scenes_f32_vs_oracle", within_1_lsb=within / total, worst_scene=worst[0], worst_what=worst[1],
            segments_ratio=seg32 / seg64)
-    assert worst[0] >= 0.90, worst
-    assert within / total >= 0.97 and abs(seg32 / seg64 - 1) < 0.02
+    # measured: 99.93 % over all scenes, 99.15 % in the worst one, segment totals equal to 7e-6
+    assert worst[0] >= 0.985, worst
+    assert within / total >= 0.998 and abs(seg32 / seg64 - 1) < 0.001
 
 
 def test_f32_image_is_independent_of_scheduling_on_random_scenes(dray, gpu):
@@ -715,7 +732,7 @@ def test_transparent_material(dray, gpu, oracle):
     col32, raw32, _, st32 = render_gpu(dray, gpu, spheres, cam)
     d = lsb_diff(col32, ocol).max(axis=-1)
     report("transparent_f32_vs_oracle", within_1_lsb=float((d <= 1).mean()), segments_f32=int(st32.segments), segments_f64=int(ost.segments))
-    assert (d <= 1).mean() >= 0.97
+    assert (d <= 1).mean() >= 0.998   # measured 99.96 %
     assert st32.segments < ost.segments   # one segment per absorbed sample instead of the depth left
     # the pixels wholly on a transparent sphere are black, and the same ones in both modes
     H, W = cam.image_height, cam.image_width
@@ -873,7 +890,7 @@ def test_bench_two_ranks_rehearsal(dray, gpu):
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                         "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
                         "--gpus", "2", "--steps", "2", "--warmup", "1", "--width", "160", "--spp", "8",
-                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=110, env=env, cwd=root)
+                        "--no-cpu-baseline", "--verify-image"], capture_output=True, text=True, timeout=110, env=env, cwd=root)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
@@ -882,6 +899,12 @@ def test_bench_two_ranks_rehearsal(dray, gpu):
     assert out["value"] > 0 and out["roofline"]["kernel_ms"] > 0
     samples = out["samples_per_s"] * out["ms_per_step"] * 1e-3 * out["steps"]
     assert abs(samples - 160 * 90 * 8 * 2) < 1.0   # both ranks' rows, both steps
+    # the image gathered from the two ranks' slabs is the image one rank renders alone, bit for bit
+    assert out["image_equals_single_rank"] is True
+    # each rank's kernel time and gather time are on the line, so imbalance and the collective's cost can be seen
+    pr = out["per_rank"]
+    assert len(pr["kernel_ms"]) == 2 and len(pr["gather_ms"]) == 2 and min(pr["kernel_ms"]) > 0
+    assert pr["kernel_ms_min"] <= pr["kernel_ms_max"] and pr["gather_ms_max"] > 0
 
 
 def test_rccl_gather_on_one_gpu(dray, gpu):
@@ -910,6 +933,48 @@ def test_rccl_gather_on_one_gpu(dray, gpu):
         scene.close()
     finally:
         dist.destroy_process_group()
+
+
+def test_headline_frame_f32_against_f64_kernel_and_oracle(dray, gpu, oracle):
+    """The measured configuration at full size: final scene, 1200 x 675, 500 samples per pixel, depth 50.  The oracle
+    cannot render 405 M samples in seconds, so the chain is: every 45th row of the f64 reference-order kernel's frame
+    equals the oracle bit for bit (sums, colours, segment count of those rows), and the f32 throughput kernel -- the
+    kernel bench.py times -- is compared with the f64 kernel's whole frame on the same Philox streams.
+    Tolerance: >= 99.99 % of the 810 000 pixels within 1 LSB on every channel, no pixel further than 4 LSB, mean
+    |diff| < 0.01 LSB, segment totals within 0.2 % (measured: 99.994 %, 4, 0.0075, +0.12 %)."""
+    spheres = dray.scene_final(1)
+    cam = dray.camera_final(width=1200, spp=500, depth=50)
+    cam.seed = 1
+    H = cam.initialize().image_height
+    assert H == 675
+    scene = gpu.DeviceScene(spheres, 0)
+    frames = {}
+    for name, mode in (("f64", dray.MODE_F64), ("f32", dray.MODE_F32)):
+        cam.mode = mode
+        color, raw, count = gpu.alloc_buffers(cam, 0)
+        st = gpu.render_device(cam, scene, color, raw, count)
+        frames[name] = (gpu.color_to_numpy(color).copy(), raw.cpu().numpy().copy(), st)
+        assert st.samples == 1200 * 675 * 500 and (count.cpu().numpy() == 500).all()
+    rows = np.arange(22, H, 45)
+    ocol, oraw, _, ost = oracle.render(ocam_from(oracle, cam), spheres, seed=1, row_begin=22, row_step=45, threads=16)
+    assert (frames["f64"][0][rows] == ocol[rows]).all() and (frames["f64"][1][rows] == oraw[rows]).all()
+    cam.mode = dray.MODE_F64
+    color, raw, count = gpu.alloc_buffers(cam, 0)
+    assert gpu.render_device(cam, scene, color, raw, count, row_begin=22, row_step=45).segments == ost.segments
+    scene.close()
+    d = lsb_diff(frames["f32"][0], frames["f64"][0])
+    worst = d.max(-1)
+    s32, s64 = int(frames["f32"][2].segments), int(frames["f64"][2].segments)
+    mse = float(np.mean((frames["f32"][1] / 500.0 - frames["f64"][1] / 500.0) ** 2))
+    report("headline_f32_vs_f64_kernel_1200x675_500spp", within_1lsb=float((worst <= 1).mean()),
+           identical=float((worst == 0).mean()), max=int(worst.max()), mean=float(d.mean()),
+           hist=[int(x) for x in np.bincount(worst.ravel(), minlength=6)[:8]], segments_f32=s32, segments_f64=s64,
+           psnr_linear_db=float(10 * np.log10(1.0 / mse)) if mse > 0 else None,
+           f64_kernel_ms=float(frames["f64"][2].kernel_ms), f32_kernel_ms=float(frames["f32"][2].kernel_ms))
+    assert (worst <= 1).mean() >= 0.9999
+    assert worst.max() <= 4
+    assert d.mean() < 0.01
+    assert abs(s32 - s64) <= 0.002 * s64
 
 
 def test_converged_image_against_independent_oracle_render(dray, gpu, oracle):
