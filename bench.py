@@ -234,9 +234,9 @@ def main():
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         total_segs, total_samples, elapsed = sums[0].item(), sums[1].item(), mx[2].item()
         mine = torch.tensor([my_kernel_ms, gather_ms], dtype=torch.float64, device=stat_dev)
-        everyone = torch.empty((world, 2), dtype=torch.float64, device=stat_dev)
+        everyone = torch.empty(world * 2, dtype=torch.float64, device=stat_dev)   # concatenated: rank r at [2r, 2r+2)
         dist.all_gather_into_tensor(everyone, mine)
-        per_rank = [tuple(r) for r in everyone.cpu().tolist()]
+        per_rank = [tuple(r) for r in everyone.view(world, 2).cpu().tolist()]
     else:
         total_segs, total_samples = float(segs), float(samples)
 

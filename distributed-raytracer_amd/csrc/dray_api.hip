@@ -640,8 +640,8 @@ int render_device_impl(const dray_camera* cam, dray_scene* scene, uint32_t* d_co
     } else {
         HIP_TRY(hipEventRecord(scene->ev[0], stream));
         if (opts.mode == DRAY_MODE_F64)
-            HIP_TRY(launch_render_ref_f64(make_cam<double>(*cam, dv), scene->dev, part, key, opts.flags, d_color, d_raw,
-                                          d_count, d_counters, stream));
+            HIP_TRY(launch_render_ref_f64(make_cam<double>(*cam, dv), scene->dev, part, key, opts.flags,
+                                          opts.variant != DRAY_SCAN_SCALAR, d_color, d_raw, d_count, d_counters, stream));
         else
             HIP_TRY(launch_render_ref_f32(make_cam<float>(*cam, dv), scene->dev, part, key, opts.flags, d_color, d_raw,
                                           d_count, d_counters, stream));
@@ -911,13 +911,14 @@ int path_step_device_impl(dray_scene* scene, int32_t image_width, dray_path_entr
         scene->last_stream = stream;
         HIP_TRY(hipMemsetAsync(scene->d_counters, 0, sizeof(DeviceCounters), stream));
         HIP_TRY(hipEventRecord(scene->ev[0], stream));
-        HIP_TRY(launch_path_step(scene->dev, key, image_width, d_entries, n, scene->d_counters, stream));
+        HIP_TRY(launch_path_step(scene->dev, key, image_width, opts.variant != DRAY_SCAN_SCALAR, d_entries, n,
+                                 scene->d_counters, stream));
         HIP_TRY(hipEventRecord(scene->ev[1], stream));
         HIP_TRY(hipEventRecord(scene->ev[2], stream));
         scene->has_last = true;
         return DRAY_OK;
     }
-    HIP_TRY(launch_path_step(scene->dev, key, image_width, d_entries, n, nullptr, stream));
+    HIP_TRY(launch_path_step(scene->dev, key, image_width, opts.variant != DRAY_SCAN_SCALAR, d_entries, n, nullptr, stream));
     return DRAY_OK;
 }
 

@@ -103,17 +103,18 @@ struct DeviceCounters {
 };
 
 // render_ref.hip
+// use_grid: find the closest hit by walking the scene's uniform grid instead of scanning the whole list (same result)
 hipError_t launch_render_ref_f64(const CamDev<double>& cam, const SceneDev& scene, const Partition& part,
-                                 const RngKey& key, uint32_t flags, uint32_t* d_color, double* d_raw, int32_t* d_count,
-                                 DeviceCounters* d_counters, hipStream_t stream);
+                                 const RngKey& key, uint32_t flags, bool use_grid, uint32_t* d_color, double* d_raw,
+                                 int32_t* d_count, DeviceCounters* d_counters, hipStream_t stream);
 hipError_t launch_render_ref_f32(const CamDev<float>& cam, const SceneDev& scene, const Partition& part,
                                  const RngKey& key, uint32_t flags, uint32_t* d_color, double* d_raw, int32_t* d_count,
                                  DeviceCounters* d_counters, hipStream_t stream);
 
 hipError_t launch_camera_rays(const CamDev<double>& cam, const RngKey& key, const dray_pixel_index* d_px, size_t n,
                               dray_path_entry* d_out, hipStream_t stream);
-hipError_t launch_path_step(const SceneDev& scene, const RngKey& key, int32_t image_width, dray_path_entry* d_entries,
-                            size_t n, DeviceCounters* d_counters, hipStream_t stream);
+hipError_t launch_path_step(const SceneDev& scene, const RngKey& key, int32_t image_width, bool use_grid,
+                            dray_path_entry* d_entries, size_t n, DeviceCounters* d_counters, hipStream_t stream);
 
 // render_f32.hip
 struct F32Plan {

@@ -70,37 +70,152 @@ template <typename T> struct Hit {
     int32_t index;
 };
 
+// What the closest-hit query reads: the sphere list, and for the f64 kernels the uniform grid the scene builder
+// lays over the list (dray_internal.h) as a way to skip spheres the ray does not come near.
+struct RefGrid {
+    GridDev grid;                // null cells: no grid
+    const int32_t* narrow_index; // grid / loose position -> position in the caller's list
+    const int32_t* wide_index;   // spheres kept out of the grid for their size
+    int32_t n_wide;
+    int32_t use;                 // 0: scan the whole list
+};
+
+// sphere.rs:28-48 for sphere k up to the choice of the root: the root the reference would accept for an upper bound
+// of +infinity, or no root.  (With a smaller bound the reference accepts the same root or none: the far root is only
+// tried when the near one is not above tmin, or not below the bound -- and then the far one is not below it either.)
+template <typename T>
+__device__ __forceinline__ bool sphere_root(const T* __restrict__ geom, int32_t k, V3<T> ro, V3<T> rd, T& root) {
+    const T tmin = (T)0.001;
+    const V3<T> center = {geom[4 * k + 0], geom[4 * k + 1], geom[4 * k + 2]};
+    const T radius = geom[4 * k + 3];
+    V3<T> oc = vsub(center, ro);
+    T a = vlen2(rd);
+    T h = vdot(rd, oc);
+    T c = vlen2(oc) - radius * radius;
+    T discriminant = h * h - a * c;
+    if (discriminant < (T)0.) return false;
+    T sqrtd = vsqrt(discriminant);
+    root = (h - sqrtd) / a;
+    if (!(tmin < root)) { // interval.rs:28-30, strict
+        root = (h + sqrtd) / a;
+        if (!(tmin < root)) return false;
+    }
+    return root < (T)INFINITY;
+}
+
+// sphere.rs:49-55 for the accepted root
+template <typename T>
+__device__ __forceinline__ void fill_hit(const T* __restrict__ geom, int32_t k, V3<T> ro, V3<T> rd, T root, Hit<T>& rec) {
+    const V3<T> center = {geom[4 * k + 0], geom[4 * k + 1], geom[4 * k + 2]};
+    const T radius = geom[4 * k + 3];
+    rec.t = root;
+    rec.p = vadd(ro, vscale(rd, root)); // ray.rs:17-19
+    V3<T> on = vdiv(vsub(rec.p, center), radius);
+    rec.front_face = vdot(rd, on) < (T)0.; // hittable.rs:16-22
+    rec.normal = rec.front_face ? on : vscale(on, (T)-1.);
+    rec.index = k;
+}
+
 // hittable_list.rs:60-74 around sphere.rs:28-57: insertion order, shrinking upper bound.
 template <typename T>
-__device__ __forceinline__ bool list_hit(const T* __restrict__ geom, int32_t n, V3<T> ro, V3<T> rd, Hit<T>& rec) {
-    bool hit_anything = false;
+__device__ __forceinline__ bool list_hit_linear(const T* __restrict__ geom, int32_t n, V3<T> ro, V3<T> rd, Hit<T>& rec) {
     T closest = (T)INFINITY;
-    const T tmin = (T)0.001;
+    int32_t best = -1;
     for (int32_t k = 0; k < n; ++k) {
-        const V3<T> center = {geom[4 * k + 0], geom[4 * k + 1], geom[4 * k + 2]};
-        const T radius = geom[4 * k + 3];
-        V3<T> oc = vsub(center, ro);
-        T a = vlen2(rd);
-        T h = vdot(rd, oc);
-        T c = vlen2(oc) - radius * radius;
-        T discriminant = h * h - a * c;
-        if (discriminant < (T)0.) continue;
-        T sqrtd = vsqrt(discriminant);
-        T root = (h - sqrtd) / a;
-        if (!(tmin < root && root < closest)) { // interval.rs:28-30, strict
-            root = (h + sqrtd) / a;
-            if (!(tmin < root && root < closest)) continue;
+        T root;
+        if (sphere_root(geom, k, ro, rd, root) && root < closest) { // strict: on equal t the earlier sphere stays
+            closest = root;
+            best = k;
         }
-        rec.t = root;
-        rec.p = vadd(ro, vscale(rd, root)); // ray.rs:17-19
-        V3<T> on = vdiv(vsub(rec.p, center), radius);
-        rec.front_face = vdot(rd, on) < (T)0.; // hittable.rs:16-22
-        rec.normal = rec.front_face ? on : vscale(on, (T)-1.);
-        rec.index = k;
-        hit_anything = true;
-        closest = root;
     }
-    return hit_anything;
+    if (best < 0) return false;
+    fill_hit(geom, best, ro, rd, closest, rec);
+    return true;
+}
+
+// The same closest hit -- smallest root, on equal roots the sphere inserted first -- found by walking the ray
+// through the uniform grid (3-D DDA in f64) and testing only the spheres listed in the cells it crosses, front to
+// back, until the best root lies before the current cell's exit.  Every sphere is tested with the reference's own
+// expressions (sphere_root), so root, point and normal are bit for bit those of the linear scan; the order in which
+// spheres are met does not matter because the minimum is taken over (root, position).  The grid lists a sphere in
+// every cell its ball grown by 1/256 of a cell overlaps, which f64 rounding of the walk cannot bridge; the wide and
+// the loose spheres are tested for every ray.  A ray that is not finite, or a walk that takes more steps than a
+// straight line can, falls back to the linear scan.
+__device__ __forceinline__ bool list_hit_grid(const double* __restrict__ geom, int32_t n, const RefGrid& rg,
+                                              V3<double> ro, V3<double> rd, Hit<double>& rec) {
+    const GridDev& g = rg.grid;
+    const double o[3] = {ro.x, ro.y, ro.z}, d[3] = {rd.x, rd.y, rd.z};
+    bool finite = true;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) finite = finite && fabs(o[a]) < 1e300 && fabs(d[a]) < 1e300; // false for NaN too
+    if (!finite) return list_hit_linear<double>(geom, n, ro, rd, rec);
+
+    double closest = INFINITY;
+    int32_t best = 0x7fffffff;
+    auto test = [&](int32_t k) {
+        double root;
+        if (sphere_root<double>(geom, k, ro, rd, root) && (root < closest || (root == closest && k < best))) {
+            closest = root;
+            best = k;
+        }
+    };
+    for (int32_t q = 0; q < rg.n_wide; ++q) test(rg.wide_index[q]);
+    for (int32_t q = 0; q < g.n_loose; ++q) test(rg.narrow_index[g.loose[q]]);
+
+    if (g.n[0] > 0) {
+        double A[3], B[3], t_in = 0., t_out = INFINITY, bmax = 0.;
+        bool inside_slabs = true;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            if (fabs(d[a]) > 1e-250) {
+                const double inv = 1.0 / d[a];
+                A[a] = (double)g.cell[a] * inv;
+                const double t0 = ((double)g.lo[a] - o[a]) * inv, t1 = ((double)g.hi[a] - o[a]) * inv;
+                B[a] = d[a] >= 0. ? t0 + A[a] : t0; // leaving cell k towards larger indices happens at plane k + 1
+                t_in = fmax(t_in, fmin(t0, t1));
+                t_out = fmin(t_out, fmax(t0, t1));
+                bmax = fmax(bmax, fmax(fabs(t0), fabs(B[a])));
+            } else { // parallel to the axis' planes: never crosses one; misses the grid if outside its slab
+                A[a] = 0.;
+                B[a] = INFINITY;
+                if (o[a] < (double)g.lo[a] || o[a] > (double)g.hi[a]) inside_slabs = false;
+            }
+        }
+        const double slack = bmax * 1e-9;
+        if (inside_slabs && t_in <= t_out + slack) {
+            int32_t c[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const double at = floor((o[a] + d[a] * t_in - (double)g.lo[a]) * (double)g.inv_cell[a]);
+                c[a] = (int32_t)fmin(fmax(at, 0.), (double)(g.n[a] - 1));
+            }
+            const int32_t max_steps = g.n[0] + g.n[1] + g.n[2] + 4;
+            int32_t steps = 0;
+            for (;; ++steps) {
+                if (steps > max_steps) return list_hit_linear<double>(geom, n, ro, rd, rec);
+                const uint2 cellrec = g.cells[((size_t)c[2] * g.n[1] + c[1]) * g.n[0] + c[0]];
+                for (uint32_t e = cellrec.x; e < cellrec.x + cellrec.y; ++e) test(rg.narrow_index[g.entry_pos[e]]);
+                const double tx = (double)c[0] * A[0] + B[0], ty = (double)c[1] * A[1] + B[1], tz = (double)c[2] * A[2] + B[2];
+                const double t_exit = fmin(tx, fmin(ty, tz));
+                if (closest < t_exit * (1. - 1e-9) - slack) break; // nothing beyond this cell can be closer
+                const int ax = (tx <= ty && tx <= tz) ? 0 : (ty <= tz ? 1 : 2);
+                c[ax] += A[ax] < 0. ? -1 : 1;
+                if (c[ax] < 0 || c[ax] >= g.n[ax]) break;
+            }
+        }
+    }
+    if (best == 0x7fffffff) return false;
+    fill_hit<double>(geom, best, ro, rd, closest, rec);
+    return true;
+}
+
+template <typename T>
+__device__ __forceinline__ bool list_hit(const T* __restrict__ geom, int32_t n, const RefGrid& rg, V3<T> ro, V3<T> rd,
+                                         Hit<T>& rec) {
+    if constexpr (sizeof(T) == sizeof(double)) {
+        if (rg.use) return list_hit_grid(geom, n, rg, ro, rd, rec);
+    }
+    return list_hit_linear<T>(geom, n, ro, rd, rec);
 }
 
 template <typename T> __device__ __forceinline__ T reflectance(T cosine, T ri) { // material.rs:93-98
@@ -185,7 +300,7 @@ __device__ __forceinline__ void get_ray(const CamDev<T>& cam, int32_t i, int32_t
 template <typename T>
 __global__ __launch_bounds__(256) void render_ref_kernel(CamDev<T> cam, const T* __restrict__ geom,
                                                          const T* __restrict__ mat, const uint32_t* __restrict__ kind,
-                                                         int32_t n, Partition part, RngKey key, uint32_t flags,
+                                                         int32_t n, RefGrid rg, Partition part, RngKey key, uint32_t flags,
                                                          uint32_t* __restrict__ color, double* __restrict__ raw,
                                                          int32_t* __restrict__ count, DeviceCounters* counters) {
     const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -214,7 +329,7 @@ __global__ __launch_bounds__(256) void render_ref_kernel(CamDev<T> cam, const T*
                 if (depth <= 0) { c = {(T)0., (T)0., (T)0.}; break; } // camera.rs:265-267 / :120-123
                 Hit<T> rec;
                 my_segments++;
-                if (list_hit<T>(geom, n, ro, rd, rec)) { // camera.rs:270
+                if (list_hit<T>(geom, n, rg, ro, rd, rec)) { // camera.rs:270
                     st.stage = (uint32_t)(cam.max_depth - depth + 1);
                     V3<T> so = ro, sd;
                     if (scatter<T>(kind[rec.index], mat + 4 * rec.index, rd, rec, st, so, sd)) {
@@ -295,8 +410,8 @@ __global__ __launch_bounds__(256) void camera_rays_kernel(CamDev<double> cam, Rn
 
 // ray_color_iteration, camera.rs:118-144: one segment of every unfinished path of the batch.
 __global__ __launch_bounds__(256) void path_step_kernel(const double* __restrict__ geom, const double* __restrict__ mat,
-                                                        const uint32_t* __restrict__ kind, int32_t n_spheres, RngKey key,
-                                                        int32_t W, dray_path_entry* __restrict__ entries, size_t n,
+                                                        const uint32_t* __restrict__ kind, int32_t n_spheres, RefGrid rg,
+                                                        RngKey key, int32_t W, dray_path_entry* __restrict__ entries, size_t n,
                                                         DeviceCounters* counters) {
     const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     unsigned long long my_segments = 0;
@@ -312,7 +427,7 @@ __global__ __launch_bounds__(256) void path_step_kernel(const double* __restrict
         } else {
             Hit<double> rec;
             my_segments = 1;
-            if (list_hit<double>(geom, n_spheres, ro, rd, rec)) { // camera.rs:126
+            if (list_hit<double>(geom, n_spheres, rg, ro, rd, rec)) { // camera.rs:126
                 const Stream st = {key.k0, key.k1, (uint32_t)e.px.pixel_j * (uint32_t)W + (uint32_t)e.px.pixel_i,
                                    key.sample_offset + (uint32_t)e.px.pixel_sample_num, e.stage};
                 V3<double> so = ro, sd;
@@ -347,9 +462,19 @@ __global__ __launch_bounds__(256) void path_step_kernel(const double* __restrict
     if ((threadIdx.x & 63) == 0 && counters && my_segments) atomicAdd(&counters->segments, my_segments);
 }
 
+RefGrid ref_grid_of(const SceneDev& scene, bool use) {
+    RefGrid rg{};
+    rg.grid = scene.grid;
+    rg.narrow_index = scene.narrow_index;
+    rg.wide_index = scene.wide_index;
+    rg.n_wide = scene.n_wide;
+    rg.use = (use && scene.narrow_index && scene.wide_index) ? 1 : 0;
+    return rg;
+}
+
 template <typename T>
 hipError_t launch_ref(const CamDev<T>& cam, const T* geom, const T* mat, const SceneDev& scene, const Partition& part,
-                      const RngKey& key, uint32_t flags, uint32_t* d_color, double* d_raw, int32_t* d_count,
+                      const RngKey& key, uint32_t flags, bool use_grid, uint32_t* d_color, double* d_raw, int32_t* d_count,
                       DeviceCounters* d_counters, hipStream_t stream) {
     const long long total = (long long)part.n_rows * cam.W;
     if (total <= 0) return hipSuccess;
@@ -357,23 +482,23 @@ hipError_t launch_ref(const CamDev<T>& cam, const T* geom, const T* mat, const S
     const long long grid = (total + block - 1) / block;
     if (grid > 0x7fffffffLL) return hipErrorInvalidValue;
     hipLaunchKernelGGL(render_ref_kernel<T>, dim3((unsigned)grid), dim3(block), 0, stream, cam, geom, mat, scene.kind,
-                       scene.n, part, key, flags, d_color, d_raw, d_count, d_counters);
+                       scene.n, ref_grid_of(scene, use_grid), part, key, flags, d_color, d_raw, d_count, d_counters);
     return hipGetLastError();
 }
 
 } // namespace
 
 hipError_t launch_render_ref_f64(const CamDev<double>& cam, const SceneDev& scene, const Partition& part,
-                                 const RngKey& key, uint32_t flags, uint32_t* d_color, double* d_raw, int32_t* d_count,
-                                 DeviceCounters* d_counters, hipStream_t stream) {
-    return launch_ref<double>(cam, scene.geom64, scene.mat64, scene, part, key, flags, d_color, d_raw, d_count,
+                                 const RngKey& key, uint32_t flags, bool use_grid, uint32_t* d_color, double* d_raw,
+                                 int32_t* d_count, DeviceCounters* d_counters, hipStream_t stream) {
+    return launch_ref<double>(cam, scene.geom64, scene.mat64, scene, part, key, flags, use_grid, d_color, d_raw, d_count,
                               d_counters, stream);
 }
 
 hipError_t launch_render_ref_f32(const CamDev<float>& cam, const SceneDev& scene, const Partition& part,
                                  const RngKey& key, uint32_t flags, uint32_t* d_color, double* d_raw, int32_t* d_count,
                                  DeviceCounters* d_counters, hipStream_t stream) {
-    return launch_ref<float>(cam, scene.geom32, scene.mat32, scene, part, key, flags, d_color, d_raw, d_count,
+    return launch_ref<float>(cam, scene.geom32, scene.mat32, scene, part, key, flags, false, d_color, d_raw, d_count,
                              d_counters, stream);
 }
 
@@ -386,13 +511,13 @@ hipError_t launch_camera_rays(const CamDev<double>& cam, const RngKey& key, cons
     return hipGetLastError();
 }
 
-hipError_t launch_path_step(const SceneDev& scene, const RngKey& key, int32_t image_width, dray_path_entry* d_entries,
-                            size_t n, DeviceCounters* d_counters, hipStream_t stream) {
+hipError_t launch_path_step(const SceneDev& scene, const RngKey& key, int32_t image_width, bool use_grid,
+                            dray_path_entry* d_entries, size_t n, DeviceCounters* d_counters, hipStream_t stream) {
     if (n == 0) return hipSuccess;
     const size_t grid = (n + 255) / 256;
     if (grid > 0x7fffffffu) return hipErrorInvalidValue;
     hipLaunchKernelGGL(path_step_kernel, dim3((unsigned)grid), dim3(256), 0, stream, scene.geom64, scene.mat64,
-                       scene.kind, scene.n, key, image_width, d_entries, n, d_counters);
+                       scene.kind, scene.n, ref_grid_of(scene, use_grid), key, image_width, d_entries, n, d_counters);
     return hipGetLastError();
 }
 

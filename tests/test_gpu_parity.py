@@ -632,7 +632,8 @@ def test_scan_variants_agree_on_random_scenes(dray, gpu):
 
 def test_f64_kernel_matches_oracle_on_random_scenes(dray, gpu, oracle):
     """The same generator against the CPU oracle: for 60 random scenes the f64 kernel's running sums, colours and
-    segment counts equal the oracle's bit for bit (both product orders alternate), and the f32 kernel on the same
+    segment counts equal the oracle's bit for bit (both product orders alternate; the closest hit found by the grid
+    walk, the default, and by the reference's scan of the whole list, DRAY_SCAN_SCALAR), and the f32 kernel on the same
     streams stays close: at least 98.5 % of the pixels within 1 LSB in every scene (2 to 4 samples per pixel: one flipped
     sample moves a pixel by tens of LSB), 99.8 % over all scenes, segment totals within 0.1 %."""
     import os
@@ -647,10 +648,12 @@ def test_f64_kernel_matches_oracle_on_random_scenes(dray, gpu, oracle):
         sp, cam, what = random_scene(rng, dray)
         cam.mode = dray.MODE_F64
         cam.flags = dray.FLAG_ITERATIVE_PRODUCT if k % 2 else 0
-        col, raw, cnt, st = render_gpu(dray, gpu, sp, cam)
+        col, raw, cnt, st = render_gpu(dray, gpu, sp, cam)   # closest hit through the grid walk
         ocol, oraw, ocnt, ost = oracle.render(ocam_from(oracle, cam), sp, seed=cam.seed, iterative=k % 2, threads=8)
         assert st.segments == ost.segments, (k, what)
         assert (raw == oraw).all() and (col == ocol).all() and (cnt == ocnt).all(), (k, what)
+        lcol, lraw, _, lst = render_gpu(dray, gpu, sp, cam, variant=dray.SCAN_SCALAR)   # and through the scan of the whole list
+        assert lst.segments == ost.segments and (lraw == oraw).all() and (lcol == ocol).all(), (k, what)
         cam.mode, cam.flags = dray.MODE_F32, 0
         col32, _, _, st32 = render_gpu(dray, gpu, sp, cam)
         ok = lsb_diff(col32, ocol).max(axis=-1) <= 1
@@ -891,7 +894,13 @@ def test_bench_two_ranks_rehearsal(dray, gpu):
                         "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
                         "--gpus", "2", "--steps", "2", "--warmup", "1", "--width", "160", "--spp", "8",
                         "--no-cpu-baseline", "--verify-image"], capture_output=True, text=True, timeout=110, env=env, cwd=root)
-    assert p.returncode == 0, p.stderr[-2000:]
+    if p.returncode != 0:
+        try:
+            with open(os.path.join(root, "gpurun_out", "rehearsal_stderr.txt"), "w") as f:
+                f.write(p.stderr)
+        except OSError:
+            pass
+    assert p.returncode == 0, p.stderr[-6000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     out = json.loads(lines[0])
