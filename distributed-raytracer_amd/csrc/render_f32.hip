@@ -59,6 +59,20 @@ constexpr int kWalkQuorum = DRAY_WALK_QUORUM;     // grid scan: lanes that must 
 #define DRAY_GRID_WAVES_PER_EU 6
 #endif
 
+// Diagnostic builds only (tools/isa_budget.py): DRAY_MARKS puts named comments into the instruction stream so that
+// instructions can be counted per section of the main loop; DRAY_SECTION_COUNTERS counts how often each section runs.
+#ifdef DRAY_MARKS
+#define DRAY_MARK(name) asm volatile("; MARK " name)
+#else
+#define DRAY_MARK(name)
+#endif
+#ifdef DRAY_SECTION_COUNTERS
+__device__ unsigned long long dray_section_counts[16];
+#define DRAY_COUNT(slot, n) (sec[slot] += (unsigned long long)(n))
+#else
+#define DRAY_COUNT(slot, n)
+#endif
+
 // Pointer into the constant address space: a wave-uniform read through it is a scalar load that the compiler
 // knows no store can alias.  The sphere tables and the kernel's own arguments are read this way.
 #define DRAY_CONSTANT __attribute__((address_space(4)))
@@ -109,7 +123,8 @@ enum { kDrawNone = 0, kDrawUnitVector = 1, kDrawUnitDisk = 2 };
 // with the smallest index.  Same streams, same attempts, same winner as the sequential loops -- in about three
 // rounds.  Requests travel through the wave's `req` slots in LDS (LDS keeps one wave's accesses in order),
 // results through lane permutes.  Returns the unit vector, or the disk point in x, y.
-__device__ __forceinline__ F3 coop_draw(const Stream& st, const uint32_t (&w)[4], uint32_t draw, uint4* req, int lane) {
+__device__ __forceinline__ F3 coop_draw(const Stream& st, const uint32_t (&w)[4], uint32_t draw, uint4* req, int lane,
+                                        uint32_t* rounds = nullptr) {
     F3 res = {0.f, 0.f, 0.f};
     bool pending = false;
     if (draw == kDrawUnitVector) {
@@ -147,6 +162,7 @@ __device__ __forceinline__ F3 coop_draw(const Stream& st, const uint32_t (&w)[4]
             pending = false;
         }
         base += 1u << shift;
+        if (rounds) ++*rounds;
     }
     return res;
 }
@@ -525,10 +541,16 @@ __device__ __forceinline__ void render_f32_body() {
     uint32_t grab_pixels = (uint32_t)a->grab_pixels;   // size of the next grab
     bool exhausted = false;
 
+#ifdef DRAY_SECTION_COUNTERS
+    unsigned long long sec[16] = {};
+#endif
     for (;;) {
         a = opaque(a);
 
         // ---- closest hit over the sphere list: hittable_list.rs:60-74 ---------------------------
+        DRAY_MARK("A_fresh_setup");
+        DRAY_COUNT(0, 1);                                          // main-loop iterations
+        DRAY_COUNT(1, __ballot(fresh) != 0ull ? 1 : 0);            // iterations that set up a scan
         n_seg += (unsigned long long)__popcll(__ballot(fresh));
         if (fresh) {
             // The origin moves along the ray up to the ball that holds the narrow spheres (the ray's parameters,
@@ -561,12 +583,16 @@ __device__ __forceinline__ void render_f32_body() {
                                  (const V4*)a->grid.entry_geom, a->grid.entry_pos};
             PathRay nray = ray;
             nray.tmin = fmaxf(ray.tmin, 0.f); // see the origin's move above
+            DRAY_MARK("B_walk_steps");
             do { // two steps per count: the count is scalar-unit work every walking lane waits for
+                DRAY_COUNT(2, 2);                                  // walk steps (wave level)
+                DRAY_COUNT(3, 2 * __popcll(__ballot(walking)));    // lanes walking at those steps
                 if (walking) walking = walk_step(gr, nray, walk);
                 if (walking) walking = walk_step(gr, nray, walk);
                 n_steps += 2u;
             } while (__popcll(__ballot(walking)) >= quorum);
         }
+        DRAY_MARK("C_hit");
 
         // ---- the hit: winner of the narrow scan against the wide spheres, point and normal --------------
         const bool shading = stage > 0 && !walking;
@@ -640,6 +666,9 @@ __device__ __forceinline__ void render_f32_body() {
 
         // ---- paths that end here without scattering: sky (camera.rs:279-281), an absorbing material
         // (material.rs:13-19), or no depth left for the scattered ray (camera.rs:265-267: its colour is 0) ------
+        DRAY_MARK("D_deposit");
+        DRAY_COUNT(4, __popcll(__ballot(shading)));                // lanes shading
+        DRAY_COUNT(5, __ballot(shading) != 0ull ? 1 : 0);          // iterations with a lane shading
         const bool ends_now = shading && (bidx < 0 || mk == DRAY_MAT_DEFAULT || stage >= a->cam.max_depth);
         if (ends_now) {
             if (bidx < 0) {
@@ -653,8 +682,10 @@ __device__ __forceinline__ void render_f32_body() {
         // ---- refill: camera.rs:217-224.  Idle lanes (their path just ended, or the launch just began) take the
         // pool's next samples; their camera ray is made further down, so that its first Philox block is evaluated
         // together with the scattering lanes' first block ----------------------------------------------
+        DRAY_MARK("E_refill");
         bool need = stage == 0 && !camera;
         unsigned long long want = __ballot(need);
+        DRAY_COUNT(6, want != 0ull ? 1 : 0);                       // iterations that refill
         // compaction switched off: the wave refills only as a whole, once its last path has ended
         if (a->no_refill != 0 && __ballot(stage > 0) != 0ull) want = 0ull;
         while (want != 0ull) {
@@ -741,6 +772,7 @@ __device__ __forceinline__ void render_f32_body() {
         // Dialectric: the reflect/refract uniform), a lane with a new sample with block 0 of stage 0 (pixel offsets,
         // first aperture attempt): one evaluation serves both.  The further attempts of the unit-vector rejection
         // sampler, and of the aperture's, are shared out over all 64 lanes, busy or not (coop_draw).
+        DRAY_MARK("F_philox_block0");
         const bool scatters = shading && !ends_now;
         const bool wants_vector = scatters && (mk == DRAY_MAT_LAMBERTIAN || mk == DRAY_MAT_METAL);
         const Stream st = {a->key.k0, a->key.k1, gpix, a->key.sample_offset + (ss & 0xFFFFFFu),
@@ -751,7 +783,17 @@ __device__ __forceinline__ void render_f32_body() {
         // defocus_angle > 0 (camera.rs:247)
         const uint32_t draw = wants_vector ? (uint32_t)kDrawUnitVector
                                            : (camera && a->cam.defocus != 0) ? (uint32_t)kDrawUnitDisk : (uint32_t)kDrawNone;
+        DRAY_MARK("G_coop_draw");
+#ifdef DRAY_SECTION_COUNTERS
+        uint32_t rounds = 0u;
+        const F3 ruv = coop_draw(st, w, draw, lds_req[wv], lane, &rounds);
+        DRAY_COUNT(7, rounds);                                     // cooperative draw rounds
+        DRAY_COUNT(8, __ballot(camera || scatters) != 0ull ? 1 : 0); // iterations that evaluate block 0
+        DRAY_COUNT(9, __popcll(__ballot(camera)));                 // camera rays made
+#else
         const F3 ruv = coop_draw(st, w, draw, lds_req[wv], lane);
+#endif
+        DRAY_MARK("H_scatter");
 
         // ---- scatter: material.rs ---------------------------------------------------------------------
         if (scatters) {
@@ -800,6 +842,7 @@ __device__ __forceinline__ void render_f32_body() {
         }
 
         // ---- camera ray of a new sample: camera.rs:238-262 --------------------------------------------
+        DRAY_MARK("I_camera_ray");
         if (camera) {
             camera_ray(&a->cam, (int32_t)ray.o.x, (int32_t)ray.o.y, w, ruv, ray);
             thr = {1.f, 1.f, 1.f};
@@ -809,7 +852,13 @@ __device__ __forceinline__ void render_f32_body() {
         }
     }
 
+    DRAY_MARK("Z_exit");
     retire_slots(0u, 0u, (uint32_t)kSlots, false);
+#ifdef DRAY_SECTION_COUNTERS
+    if (lane == 0)
+        for (int q = 0; q < 16; ++q)
+            if (sec[q]) atomicAdd(&dray_section_counts[q], sec[q]);
+#endif
 
     if (lane == 0) {
         atomicAdd(&a->counters->segments, n_seg);
@@ -963,6 +1012,15 @@ hipError_t launch_render_f32(const CamDev<float>& cam, const SceneDev& scene, co
         launch(render_f32_kernel<kScanScalar>);
     return hipGetLastError();
 }
+
+#ifdef DRAY_SECTION_COUNTERS
+// Diagnostic builds only: reads and clears the section counters.
+extern "C" int dray_debug_section_counts(unsigned long long* out) {
+    unsigned long long zero[16] = {};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(dray_section_counts), sizeof zero) != hipSuccess) return -1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(dray_section_counts), zero, sizeof zero) == hipSuccess ? 0 : -1;
+}
+#endif
 
 hipError_t launch_resolve_f32(const CamDev<float>& cam, const Partition& part, const unsigned long long* d_accum,
                               uint32_t* d_color, double* d_raw, int32_t* d_count, hipStream_t stream) {
