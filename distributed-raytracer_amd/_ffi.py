@@ -27,6 +27,7 @@ NOALLOC_MAX_PIXELS = 1048576
 
 MAT_DEFAULT, MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC, MAT_TRANSPARENT = 0, 1, 2, 3, 4
 MODE_F64, MODE_F32, MODE_F32_PLAIN = 0, 1, 2
+SHAPE_SPHERE, SHAPE_BOX = 0, 1
 FLAG_ITERATIVE_PRODUCT = 1
 FLAG_COMPACT_ROWS = 2
 FLAG_NO_REFILL = 4
@@ -73,14 +74,14 @@ class SpherePOD(C.Structure):
         ("center", D3),
         ("radius", C.c_double),
         ("kind", C.c_uint32),
-        ("_pad", C.c_uint32),
+        ("shape", C.c_uint32),
         ("albedo", D3),
         ("fuzz_or_ior", C.c_double),
     ]
 
 
 SPHERE_DTYPE = np.dtype(
-    [("center", "<f8", 3), ("radius", "<f8"), ("kind", "<u4"), ("_pad", "<u4"), ("albedo", "<f8", 3),
+    [("center", "<f8", 3), ("radius", "<f8"), ("kind", "<u4"), ("shape", "<u4"), ("albedo", "<f8", 3),
      ("fuzz_or_ior", "<f8")]
 )
 assert SPHERE_DTYPE.itemsize == C.sizeof(SpherePOD) == 72

@@ -94,6 +94,11 @@ void stv(double* p, D3 a) { p[0] = a.x; p[1] = a.y; p[2] = a.z; }
 
 double degrees_to_radians(double d) { return d * 3.14159265358979323846264338327950288 / 180.0; } // prelude.rs:17-20
 
+// the list entries the library has a device form for: spheres of the five materials, and bounding boxes
+bool entry_ok(const dray_sphere& e) {
+    return e.shape == DRAY_SHAPE_BOX || (e.shape == DRAY_SHAPE_SPHERE && e.kind <= DRAY_MAT_TRANSPARENT);
+}
+
 bool camera_ok(const dray_camera* cam) {
     return cam && cam->image_width >= 1 && std::isfinite(cam->aspect_ratio) && cam->aspect_ratio > 0.;
 }
@@ -164,6 +169,7 @@ void scene_free(dray_scene* s) {
     (void)hipFree(d.narrow_geom); (void)hipFree(d.filter_xy); (void)hipFree(d.filter_zn);
     (void)hipFree(d.narrow_index); (void)hipFree(d.wide_index);
     (void)hipFree(d.grid_cells); (void)hipFree(d.grid_entry_geom); (void)hipFree(d.grid_entry_pos); (void)hipFree(d.grid_loose);
+    (void)hipFree(d.box64); (void)hipFree(d.box_index);
     (void)hipFree(s->d_counters); (void)hipFree(s->d_accum);
     for (auto& e : s->ev)
         if (e) (void)hipEventDestroy(e);
@@ -344,6 +350,7 @@ int upload(T** dst, const std::vector<T>& src) {
 void classify_spheres(const dray_sphere* sp, size_t n, std::vector<float>& ng, std::vector<int32_t>& nidx,
                       std::vector<int32_t>& widx) {
     for (size_t k = 0; k < n; ++k) {
+        if (sp[k].shape == DRAY_SHAPE_BOX) continue; // a bounding box: in neither sphere list
         const double r = std::fmax(sp[k].radius, 0.); // sphere.rs:14
         if (r >= kWideRadius) {
             widx.push_back((int32_t)k);
@@ -359,7 +366,7 @@ int grid_inspect_impl(const dray_sphere* sp, size_t n, dray_grid_info* info, uin
                       int32_t* loose_sphere) {
     if (!info || (!sp && n) || n > 0x7fffffffu) return DRAY_ERR_INVALID_ARG;
     for (size_t k = 0; k < n; ++k) // the lists dray_scene_create takes, and no others
-        if (sp[k].kind > DRAY_MAT_TRANSPARENT) return DRAY_ERR_UNSUPPORTED;
+        if (!entry_ok(sp[k])) return DRAY_ERR_UNSUPPORTED;
     std::vector<float> ng;
     std::vector<int32_t> nidx, widx;
     classify_spheres(sp, n, ng, nidx, widx);
@@ -396,7 +403,7 @@ int scene_create_impl(const dray_sphere* sp, size_t n, int32_t device, dray_scen
     if (device < 0) HIP_TRY(hipGetDevice(&device));
     if (device >= ndev) return DRAY_ERR_INVALID_ARG;
     for (size_t k = 0; k < n; ++k)
-        if (sp[k].kind > DRAY_MAT_TRANSPARENT) return DRAY_ERR_UNSUPPORTED;
+        if (!entry_ok(sp[k])) return DRAY_ERR_UNSUPPORTED;
 
     DeviceGuard g(device);
     if (g.err != hipSuccess) return hip_fail(g.err, "hipSetDevice");
@@ -410,7 +417,25 @@ int scene_create_impl(const dray_sphere* sp, size_t n, int32_t device, dray_scen
     std::vector<float> g32(4 * n), m32(4 * n), ng;
     std::vector<uint32_t> kind(n);
     std::vector<int32_t> nidx, widx;
+    std::vector<double> box64;
+    std::vector<int32_t> box_index;
     for (size_t k = 0; k < n; ++k) {
+        if (sp[k].shape == DRAY_SHAPE_BOX) {
+            // the box itself goes to the box table; its row in the sphere tables is a sphere that no ray hits (the
+            // discriminant of a NaN centre is NaN, and every comparison with the root fails), its material
+            // Transparent (bounding_box.rs:65,71)
+            const dray_box& b = reinterpret_cast<const dray_box&>(sp[k]);
+            for (int q = 0; q < 3; ++q) box64.push_back(b.min[q]);
+            for (int q = 0; q < 3; ++q) box64.push_back(b.max[q]);
+            box_index.push_back((int32_t)k);
+            for (int q = 0; q < 3; ++q) {
+                g64[4 * k + q] = NAN; g32[4 * k + q] = NAN;
+                m64[4 * k + q] = 0.; m32[4 * k + q] = 0.f;
+            }
+            g64[4 * k + 3] = 0.; g32[4 * k + 3] = 0.f; m64[4 * k + 3] = 0.; m32[4 * k + 3] = 0.f;
+            kind[k] = DRAY_MAT_TRANSPARENT;
+            continue;
+        }
         const double r = std::fmax(sp[k].radius, 0.); // sphere.rs:14
         double f = sp[k].fuzz_or_ior;
         if (sp[k].kind == DRAY_MAT_METAL) f = f < 1.0 ? f : 1.0; // material.rs:67
@@ -469,6 +494,11 @@ int scene_create_impl(const dray_sphere* sp, size_t n, int32_t device, dray_scen
     std::vector<uint32_t> kind32(kind);
     for (uint32_t& k : kind32)
         if (k == DRAY_MAT_TRANSPARENT) k = DRAY_MAT_DEFAULT;
+    d.n_boxes = (int32_t)box_index.size();
+    if ((rc = upload(&d.box64, box64)) || (rc = upload(&d.box_index, box_index))) {
+        scene_free(s);
+        return rc;
+    }
     if ((rc = upload(&d.geom64, g64)) || (rc = upload(&d.mat64, m64)) || (rc = upload(&d.kind, kind)) ||
         (rc = upload(&d.kind32, kind32)) ||
         (rc = upload(&d.geom32, g32)) || (rc = upload(&d.mat32, m32)) || (rc = upload(&d.narrow_geom, ng)) ||
@@ -814,7 +844,7 @@ int render_multi_impl(const dray_camera* cam, const dray_sphere* spheres, size_t
         devs.push_back(d);
     }
     for (size_t k = 0; k < n; ++k)
-        if (spheres[k].kind > DRAY_MAT_TRANSPARENT) return DRAY_ERR_UNSUPPORTED;
+        if (!entry_ok(spheres[k])) return DRAY_ERR_UNSUPPORTED;
     dray_camera_derived dv;
     int rc = dray_camera_initialize(cam, &dv);
     if (rc) return rc;

@@ -81,6 +81,11 @@ struct SceneDev {
     int32_t* narrow_index = nullptr;
     int32_t* wide_index = nullptr;
     F32Tables f32; // the pointers above, as the f32 kernel takes them
+    // list entries that are bounding boxes (bounding_box.rs): min xyz, max xyz per box, and their list positions.
+    // In the sphere tables such an entry is a sphere no ray can hit (NaN centre), its kind is Transparent.
+    int32_t n_boxes = 0;
+    double* box64 = nullptr;      // n_boxes x 6
+    int32_t* box_index = nullptr; // n_boxes, ascending
     // grid scan
     uint2* grid_cells = nullptr;
     float* grid_entry_geom = nullptr;

@@ -421,6 +421,9 @@ struct F32Args {
     const V4* mat32;
     const uint32_t* kind;
     int32_t n_narrow_padded, n_wide;
+    const double* box64;      // bounding boxes of the list: min xyz, max xyz (kernels built with BOXES only)
+    const int32_t* box_index; // their positions in the caller's list, ascending
+    int32_t n_boxes;
     float bound[4]; // F32Tables::bound
     GridDev grid;
     Partition part;
@@ -440,7 +443,10 @@ __device__ __forceinline__ ConstPtr<T> opaque(ConstPtr<T> p) {
     return (ConstPtr<T>)v;
 }
 
-template <int SCAN>
+// BOXES: the list holds bounding boxes (bounding_box.rs) beside its spheres.  Such a kernel carries two more values
+// per lane (the closest box of the lane's ray), so scenes without boxes -- all of the reference's render scenes --
+// run the kernels built without.
+template <int SCAN, bool BOXES>
 __device__ __forceinline__ void render_f32_body() {
     // The arguments (some sixty scalar registers' worth) are read where they are used, straight from the kernel
     // argument segment, and the pointer to it is made opaque once per path segment.  Left to itself the compiler
@@ -530,6 +536,8 @@ __device__ __forceinline__ void render_f32_body() {
     bool walking = false; // grid scan: the lane is on its way through the grid
     ScanBest sb = {INFINITY, -1, false};
     Walk walk = {};
+    float box_t = INFINITY; // BOXES: distance of the closest box along the lane's ray, and the box's list position
+    int32_t box_idx = -1;
     // wave-uniform queue state
     uint32_t pool_pix = 0u, pool_q = 0u, pool_n = 0u; // first pixel, next sample, sample count of the pool
     uint32_t pool_r0 = 0u, pool_i0 = 0u;               // row and column of the pool's first pixel in the partition
@@ -559,11 +567,45 @@ __device__ __forceinline__ void render_f32_body() {
             // accepts spheres the ray passes at a distance (0.02 units at |oc| = 50), and which of those a scan meets
             // depends on the scan.  From the ball's rim |oc| is at most its diameter.  Nothing narrow lies before the
             // rim, so the narrow tests may take max(tmin, 0) for their lower bound; the wide spheres keep tmin.
+            if constexpr (BOXES) {
+                // BoundingBox::hit, bounding_box.rs:50-76, in f64 as it is written: axes 0 and 1 only (:53), plane
+                // distances `min - origin / direction` (:55-56) -- which are not invariant under scaling the direction,
+                // so the reference's un-normalised direction is rebuilt from the unit one (tmin = 0.001 |direction|).
+                // Tested here because the origin is about to be moved.  Distances come out in units of the unit direction.
+                box_t = INFINITY;
+                box_idx = -1;
+                const double len = (double)(ray.tmin * 1000.f);
+                const double bo[2] = {(double)ray.o.x, (double)ray.o.y};
+                const double bd[2] = {(double)ray.d.x * len, (double)ray.d.y * len};
+                ConstPtr<double> box64 = as_constant(a->box64);
+                for (int32_t q = 0; q < a->n_boxes; ++q) { // wave-uniform
+                    double t_min = -INFINITY, t_max = INFINITY;
+#pragma unroll
+                    for (int ax = 0; ax < 2; ++ax) {
+                        if (bd[ax] != 0.0) {
+                            const double t0 = box64[6 * q + ax] - bo[ax] / bd[ax];
+                            const double t1 = box64[6 * q + 3 + ax] - bo[ax] / bd[ax];
+                            t_min = fmax(t_min, fmin(t0, t1));
+                            t_max = fmin(t_max, fmax(t0, t1));
+                        }
+                    }
+                    if (t_max >= t_min) {
+                        double t = t_min;
+                        if (!(0.001 < t)) t = t_max; // interval.rs:28-30
+                        const float tu = (float)(t * len);
+                        if (0.001 < t && tu < box_t) { // ascending list positions: on equal distance the earlier box stays
+                            box_t = tu;
+                            box_idx = as_constant(a->box_index)[q];
+                        }
+                    }
+                }
+            }
             {
                 const float bx = a->bound[0] - ray.o.x, by = a->bound[1] - ray.o.y, bz = a->bound[2] - ray.o.z;
                 const float s = fmaxf(fmaf(bz, ray.d.z, fmaf(by, ray.d.y, bx * ray.d.x)) - a->bound[3], 0.f);
                 ray.o = {fmaf(s, ray.d.x, ray.o.x), fmaf(s, ray.d.y, ray.o.y), fmaf(s, ray.d.z, ray.o.z)};
                 ray.tmin -= s;
+                if constexpr (BOXES) box_t -= s; // distances are counted from the origin: it has just moved by s
             }
             PathRay nray = ray;
             nray.tmin = fmaxf(ray.tmin, 0.f);
@@ -656,6 +698,14 @@ __device__ __forceinline__ void render_f32_body() {
                         const float ir = rcp((float)rad);
                         hn = {(float)(px - cx) * ir, (float)(py - cy) * ir, (float)(pz - cz) * ir}; // sphere.rs:52
                     }
+                }
+            }
+            if constexpr (BOXES) {
+                // a box in front of the closest sphere (on equal distance: earlier in the list) is what the ray hits; its
+                // material, Transparent, makes the sample black (its kind in this kernel's table is the absorber's)
+                if (box_idx >= 0 && (box_t < best || (box_t == best && box_idx < bidx))) {
+                    best = box_t;
+                    bidx = box_idx;
                 }
             }
             if (bidx >= 0) {
@@ -867,17 +917,23 @@ __device__ __forceinline__ void render_f32_body() {
     }
 }
 
-// The three kernels differ in the sphere scan and in the register budget that suits it.  The argument block is
-// only ever read through the kernel-argument segment pointer (see render_f32_body).
-template <int SCAN>
+// The kernels differ in the sphere scan and in the register budget that suits it (and in whether the list holds
+// bounding boxes).  The argument block is only ever read through the kernel-argument segment pointer (see
+// render_f32_body).
+template <int SCAN, bool BOXES>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DRAY_WAVES_PER_EU, DRAY_WAVES_PER_EU))) void render_f32_kernel(
     F32Args) {
-    render_f32_body<SCAN>();
+    render_f32_body<SCAN, BOXES>();
 }
 template <>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DRAY_GRID_WAVES_PER_EU, DRAY_GRID_WAVES_PER_EU))) void render_f32_kernel<kScanGrid>(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DRAY_GRID_WAVES_PER_EU, DRAY_GRID_WAVES_PER_EU))) void render_f32_kernel<kScanGrid, false>(
     F32Args) {
-    render_f32_body<kScanGrid>();
+    render_f32_body<kScanGrid, false>();
+}
+template <>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DRAY_GRID_WAVES_PER_EU, DRAY_GRID_WAVES_PER_EU))) void render_f32_kernel<kScanGrid, true>(
+    F32Args) {
+    render_f32_body<kScanGrid, true>();
 }
 
 // Adds the fixed-point sums into the caller's buffers and writes the packed colour: colors.rs:38-43.
@@ -908,7 +964,7 @@ __global__ __launch_bounds__(256) void resolve_f32_kernel(int32_t W, int32_t spp
 
 template <int SCAN>
 hipError_t occupancy_of(int* occ, int block, size_t lds) {
-    return hipOccupancyMaxActiveBlocksPerMultiprocessor(occ, render_f32_kernel<SCAN>, block, lds);
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(occ, render_f32_kernel<SCAN, false>, block, lds);
 }
 
 F32Plan plan_render_f32(const CamDev<float>& cam, const Partition& part, int32_t pixels_per_pool, int32_t variant,
@@ -996,6 +1052,7 @@ hipError_t launch_render_f32(const CamDev<float>& cam, const SceneDev& scene, co
     args.narrow_index = t.narrow_index; args.wide_index = t.wide_index;
     args.geom64 = t.geom64; args.geom32 = (const V4*)t.geom32; args.mat32 = (const V4*)t.mat32; args.kind = t.kind;
     args.n_narrow_padded = t.n_narrow_padded; args.n_wide = t.n_wide;
+    args.box64 = scene.box64; args.box_index = scene.box_index; args.n_boxes = scene.n_boxes;
     for (int q = 0; q < 4; ++q) args.bound[q] = t.bound[q];
     args.grid = scene.grid;
     args.part = part; args.key = key; args.pixels_per_pool = plan.pixels_per_pool; args.grab_pixels = plan.grab_pixels;
@@ -1004,12 +1061,13 @@ hipError_t launch_render_f32(const CamDev<float>& cam, const SceneDev& scene, co
     auto launch = [&](auto kernel) {
         hipLaunchKernelGGL(kernel, dim3(plan.grid), dim3(plan.block), plan.lds_bytes, stream, args);
     };
+    const bool boxes = scene.n_boxes > 0;
     if (plan.scan == DRAY_SCAN_HYBRID)
-        launch(render_f32_kernel<kScanHybrid>);
+        boxes ? launch(render_f32_kernel<kScanHybrid, true>) : launch(render_f32_kernel<kScanHybrid, false>);
     else if (plan.scan == DRAY_SCAN_GRID)
-        launch(render_f32_kernel<kScanGrid>);
+        boxes ? launch(render_f32_kernel<kScanGrid, true>) : launch(render_f32_kernel<kScanGrid, false>);
     else
-        launch(render_f32_kernel<kScanScalar>);
+        boxes ? launch(render_f32_kernel<kScanScalar, true>) : launch(render_f32_kernel<kScanScalar, false>);
     return hipGetLastError();
 }
 

@@ -78,7 +78,62 @@ struct RefGrid {
     const int32_t* wide_index;   // spheres kept out of the grid for their size
     int32_t n_wide;
     int32_t use;                 // 0: scan the whole list
+    // list entries that are bounding boxes: min xyz, max xyz, and the entry's position in the list
+    const double* box64;
+    const int32_t* box_index;
+    int32_t n_boxes;
 };
+
+// BoundingBox::hit, bounding_box.rs:50-76, up to the choice of the root, for an upper bound of +infinity (a smaller
+// bound accepts the same root or none, as for a sphere: t_max >= t_min).  As written there: only axes 0 and 1 are
+// looked at (:53), a plane's distance is `min - origin / direction` (:55-56), and f64::max / f64::min return the
+// other operand when one is NaN, as fmax / fmin do.
+template <typename T>
+__device__ __forceinline__ bool box_root(const double* __restrict__ box, V3<T> ro, V3<T> rd, T& root) {
+    const T tmin = (T)0.001;
+    T t_min = -(T)INFINITY, t_max = (T)INFINITY;
+    const T o[2] = {ro.x, ro.y}, d[2] = {rd.x, rd.y};
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        if (d[a] != (T)0.0) {
+            T t0 = (T)box[a] - o[a] / d[a];
+            T t1 = (T)box[3 + a] - o[a] / d[a];
+            t_min = fmax(t_min, fmin(t0, t1));
+            t_max = fmin(t_max, fmax(t0, t1));
+        }
+    }
+    if (!(t_max >= t_min)) return false;
+    root = t_min;
+    if (!(tmin < root)) { // interval.rs:28-30, strict
+        root = t_max;
+        if (!(tmin < root)) return false;
+    }
+    return root < (T)INFINITY;
+}
+
+// The boxes of the list against the closest sphere hit so far: smallest root, on equal roots the earlier entry.
+// A box hit sets t and p (bounding_box.rs:63-64); its material reads neither normal nor face.
+template <typename T>
+__device__ __forceinline__ bool boxes_hit(const RefGrid& rg, V3<T> ro, V3<T> rd, T closest, int32_t best, Hit<T>& rec) {
+    bool any = false;
+    for (int32_t q = 0; q < rg.n_boxes; ++q) {
+        const int32_t k = rg.box_index[q];
+        T root;
+        if (box_root<T>(rg.box64 + 6 * q, ro, rd, root) && (root < closest || (root == closest && k < best))) {
+            closest = root;
+            best = k;
+            any = true;
+        }
+    }
+    if (any) {
+        rec.t = closest;
+        rec.p = vadd(ro, vscale(rd, closest)); // ray.rs:17-19
+        rec.normal = {(T)0., (T)0., (T)0.};
+        rec.front_face = false;
+        rec.index = best;
+    }
+    return any;
+}
 
 // sphere.rs:28-48 for sphere k up to the choice of the root: the root the reference would accept for an upper bound
 // of +infinity, or no root.  (With a smaller bound the reference accepts the same root or none: the far root is only
@@ -118,9 +173,10 @@ __device__ __forceinline__ void fill_hit(const T* __restrict__ geom, int32_t k, 
 
 // hittable_list.rs:60-74 around sphere.rs:28-57: insertion order, shrinking upper bound.
 template <typename T>
-__device__ __forceinline__ bool list_hit_linear(const T* __restrict__ geom, int32_t n, V3<T> ro, V3<T> rd, Hit<T>& rec) {
+__device__ __forceinline__ bool list_hit_linear(const T* __restrict__ geom, int32_t n, const RefGrid& rg, V3<T> ro,
+                                                V3<T> rd, Hit<T>& rec) {
     T closest = (T)INFINITY;
-    int32_t best = -1;
+    int32_t best = 0x7fffffff;
     for (int32_t k = 0; k < n; ++k) {
         T root;
         if (sphere_root(geom, k, ro, rd, root) && root < closest) { // strict: on equal t the earlier sphere stays
@@ -128,7 +184,8 @@ __device__ __forceinline__ bool list_hit_linear(const T* __restrict__ geom, int3
             best = k;
         }
     }
-    if (best < 0) return false;
+    if (boxes_hit<T>(rg, ro, rd, closest, best, rec)) return true;
+    if (best == 0x7fffffff) return false;
     fill_hit(geom, best, ro, rd, closest, rec);
     return true;
 }
@@ -148,7 +205,7 @@ __device__ __forceinline__ bool list_hit_grid(const double* __restrict__ geom, i
     bool finite = true;
 #pragma unroll
     for (int a = 0; a < 3; ++a) finite = finite && fabs(o[a]) < 1e300 && fabs(d[a]) < 1e300; // false for NaN too
-    if (!finite) return list_hit_linear<double>(geom, n, ro, rd, rec);
+    if (!finite) return list_hit_linear<double>(geom, n, rg, ro, rd, rec);
 
     double closest = INFINITY;
     int32_t best = 0x7fffffff;
@@ -192,7 +249,7 @@ __device__ __forceinline__ bool list_hit_grid(const double* __restrict__ geom, i
             const int32_t max_steps = g.n[0] + g.n[1] + g.n[2] + 4;
             int32_t steps = 0;
             for (;; ++steps) {
-                if (steps > max_steps) return list_hit_linear<double>(geom, n, ro, rd, rec);
+                if (steps > max_steps) return list_hit_linear<double>(geom, n, rg, ro, rd, rec);
                 const uint2 cellrec = g.cells[((size_t)c[2] * g.n[1] + c[1]) * g.n[0] + c[0]];
                 for (uint32_t e = cellrec.x; e < cellrec.x + cellrec.y; ++e) test(rg.narrow_index[g.entry_pos[e]]);
                 const double tx = (double)c[0] * A[0] + B[0], ty = (double)c[1] * A[1] + B[1], tz = (double)c[2] * A[2] + B[2];
@@ -204,6 +261,7 @@ __device__ __forceinline__ bool list_hit_grid(const double* __restrict__ geom, i
             }
         }
     }
+    if (boxes_hit<double>(rg, ro, rd, closest, best, rec)) return true;
     if (best == 0x7fffffff) return false;
     fill_hit<double>(geom, best, ro, rd, closest, rec);
     return true;
@@ -215,7 +273,7 @@ __device__ __forceinline__ bool list_hit(const T* __restrict__ geom, int32_t n, 
     if constexpr (sizeof(T) == sizeof(double)) {
         if (rg.use) return list_hit_grid(geom, n, rg, ro, rd, rec);
     }
-    return list_hit_linear<T>(geom, n, ro, rd, rec);
+    return list_hit_linear<T>(geom, n, rg, ro, rd, rec);
 }
 
 template <typename T> __device__ __forceinline__ T reflectance(T cosine, T ri) { // material.rs:93-98
@@ -469,6 +527,9 @@ RefGrid ref_grid_of(const SceneDev& scene, bool use) {
     rg.wide_index = scene.wide_index;
     rg.n_wide = scene.n_wide;
     rg.use = (use && scene.narrow_index && scene.wide_index) ? 1 : 0;
+    rg.box64 = scene.box64;
+    rg.box_index = scene.box_index;
+    rg.n_boxes = scene.n_boxes;
     return rg;
 }
 

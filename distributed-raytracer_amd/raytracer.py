@@ -90,6 +90,28 @@ class Sphere(Hittable):
         out.append((self._center, self._radius, self._mat.kind, 0, self._mat.albedo, self._mat.param))
 
 
+class BoundingBox(Hittable):
+    """bounding_box.rs:6-28: three intervals.  As a hittable it is intersected the way bounding_box.rs:50-76 is
+    written (axes 0 and 1 only, plane distance ``min - origin / direction``) and its material is always Transparent."""
+
+    def __init__(self, axes=None):
+        inf = float("inf")
+        axes = [(inf, -inf)] * 3 if axes is None else [(float(lo), float(hi)) for lo, hi in axes]  # default: EMPTY
+        if len(axes) != 3:
+            raise ValueError("expected 3 intervals")
+        self.axes = axes
+
+    @classmethod
+    def new_xyz(cls, x_min, x_max, y_min, y_max, z_min, z_max):
+        return cls([(x_min, x_max), (y_min, y_max), (z_min, z_max)])
+
+    def flatten(self, out):
+        lo = tuple(a[0] for a in self.axes)
+        hi = tuple(a[1] for a in self.axes)
+        # a dray_box record in a dray_sphere's place: min in `center`, max in `albedo`, shape = box
+        out.append((lo, 0.0, 0, _ffi.SHAPE_BOX, hi, 0.0))
+
+
 class HittableList(Hittable):
     def __init__(self, objects=None):
         self.objects = list(objects) if objects is not None else []

@@ -83,10 +83,26 @@ typedef struct dray_sphere {
     double center[3];
     double radius;
     uint32_t kind;
-    uint32_t _pad;
+    uint32_t shape;     /* DRAY_SHAPE_SPHERE (0), or DRAY_SHAPE_BOX: the record is a dray_box */
     double albedo[3];   /* Lambertian / Metal */
     double fuzz_or_ior; /* Metal: fuzz; Dialectric: refraction index */
 } dray_sphere;
+
+/* A BoundingBox (bounding_box.rs:6-9: three Intervals) as an entry of the hittable list: a record of the size of a
+ * dray_sphere with `shape` at the same place, passed in the same array at its place in the insertion order.  It is
+ * intersected as bounding_box.rs:50-76 is written -- only axes 0 and 1 are looked at (:53) and a plane's distance is
+ * `min - origin / direction` (:55-56) -- and its material is always Transparent (:65,71), which hands the incoming ray
+ * back: a path that meets a box first walks through the depth it has left and ends black.  The reference-order modes
+ * do exactly that; DRAY_MODE_F32 renders the sample black at once (as it does for Transparent spheres). */
+enum { DRAY_SHAPE_SPHERE = 0, DRAY_SHAPE_BOX = 1 };
+typedef struct dray_box {
+    double min[3];         /* axes[a].min */
+    double _unused0;
+    uint32_t _unused_kind;
+    uint32_t shape;        /* DRAY_SHAPE_BOX */
+    double max[3];         /* axes[a].max */
+    double _unused1;
+} dray_box;
 
 /* Arithmetic of the render. */
 enum {

@@ -14,7 +14,9 @@
 #pragma once
 
 #include <algorithm>
+#include <cmath>
 #include <cstdint>
+#include <cstring>
 #include <memory>
 #include <random>
 #include <stdexcept>
@@ -127,6 +129,28 @@ class Sphere : public Hittable {
     Point3 center_;
     double radius_;
     std::shared_ptr<Material> mat_;
+};
+
+// bounding_box.rs:6-28: three intervals.  As a hittable it is intersected the way bounding_box.rs:50-76 is written
+// (axes 0 and 1 only) and its material is always Transparent.
+class BoundingBox : public Hittable {
+  public:
+    BoundingBox() // BoundingBox::default: three empty intervals (interval.rs: EMPTY = (+inf, -inf))
+        : BoundingBox(INFINITY, -INFINITY, INFINITY, -INFINITY, INFINITY, -INFINITY) {}
+    BoundingBox(double x_min, double x_max, double y_min, double y_max, double z_min, double z_max) // new_xyz
+        : min_{x_min, y_min, z_min}, max_{x_max, y_max, z_max} {}
+    void flatten(std::vector<dray_sphere>& out) const override {
+        dray_box b{};
+        for (int a = 0; a < 3; ++a) { b.min[a] = min_[a]; b.max[a] = max_[a]; }
+        b.shape = DRAY_SHAPE_BOX;
+        dray_sphere s;
+        static_assert(sizeof(dray_box) == sizeof(dray_sphere), "a box record takes a sphere's place in the list");
+        std::memcpy(&s, &b, sizeof s);
+        out.push_back(s);
+    }
+
+  private:
+    double min_[3], max_[3];
 };
 
 class HittableList : public Hittable {

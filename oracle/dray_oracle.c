@@ -214,8 +214,36 @@ int orc_sphere_hit(const orc_sphere* s, const double* ro, const double* rd, doub
     return 1;
 }
 
+/* BoundingBox::hit, bounding_box.rs:50-76.  The loop covers axes 0 and 1 only (:53), the plane distances are
+ * `min - origin / direction` (:55-56; the division binds tighter than the subtraction), f64::max / f64::min return
+ * the other operand when one is NaN (fmax / fmin do the same), and only t and p of the record are written: normal and
+ * front_face stay what the record held (its material, Transparent, reads neither). */
+int orc_box_hit(const orc_box* b, const double* ro, const double* rd, double tmin, double tmax, orc_hit* rec) {
+    double t_min = -INFINITY, t_max = INFINITY;
+    for (int a = 0; a < 2; ++a) {
+        if (rd[a] != 0.0) {
+            double t0 = b->min[a] - ro[a] / rd[a];
+            double t1 = b->max[a] - ro[a] / rd[a];
+            t_min = fmax(t_min, fmin(t0, t1));
+            t_max = fmin(t_max, fmax(t0, t1));
+        }
+    }
+    if (t_max >= t_min) {
+        double t;
+        if (orc_surrounds(tmin, tmax, t_min)) t = t_min;
+        else if (orc_surrounds(tmin, tmax, t_max)) t = t_max;
+        else return 0;
+        rec->t = t;
+        double td[3];
+        orc_v_scale(rd, t, td); /* ray.rs:17-19 */
+        orc_v_add(ro, td, rec->p);
+        return 1;
+    }
+    return 0;
+}
+
 /* hittable_list.rs:60-74: insertion order, shrinking upper bound, strict compare
- * (on equal t the earlier sphere stays). */
+ * (on equal t the earlier object stays). */
 int orc_list_hit(const orc_sphere* s, size_t n, const double* ro, const double* rd, double tmin, double tmax,
                  orc_hit* rec) {
     orc_hit tmp;
@@ -223,7 +251,9 @@ int orc_list_hit(const orc_sphere* s, size_t n, const double* ro, const double* 
     int hit_anything = 0;
     double closest = tmax;
     for (size_t k = 0; k < n; ++k) {
-        if (orc_sphere_hit(&s[k], ro, rd, tmin, closest, &tmp)) {
+        const int hit = s[k].shape == ORC_SHAPE_BOX ? orc_box_hit((const orc_box*)&s[k], ro, rd, tmin, closest, &tmp)
+                                                    : orc_sphere_hit(&s[k], ro, rd, tmin, closest, &tmp);
+        if (hit) {
             hit_anything = 1;
             closest = tmp.t;
             tmp.index = (int32_t)k;
@@ -294,7 +324,7 @@ int orc_scatter(const orc_sphere* s, const double* rd, const orc_hit* rec, orc_r
  * other material scatters from the hit point (orc_scatter). */
 static int scatter_from(const orc_sphere* s, const double* ro, const double* rd, const orc_hit* rec, orc_rng* rng,
                         double* att, double* so, double* sd) {
-    if (s->kind == ORC_MAT_TRANSPARENT) {
+    if (s->kind == ORC_MAT_TRANSPARENT || s->shape == ORC_SHAPE_BOX) { /* a box's material: bounding_box.rs:65,71 */
         att[0] = 1.0; att[1] = 1.0; att[2] = 1.0;
         so[0] = ro[0]; so[1] = ro[1]; so[2] = ro[2];
         sd[0] = rd[0]; sd[1] = rd[1]; sd[2] = rd[2];

@@ -67,10 +67,22 @@ typedef struct orc_sphere {
     double center[3];
     double radius;
     uint32_t kind;
-    uint32_t _pad;
+    uint32_t shape; /* ORC_SHAPE_SPHERE, or ORC_SHAPE_BOX: the record is an orc_box */
     double albedo[3];
     double fuzz_or_ior;
 } orc_sphere;
+
+/* A list entry that is a BoundingBox (src/raytracer/bounding_box.rs:6-9: three Intervals) instead of a Sphere:
+ * same size as orc_sphere, `shape` at the same place.  Its material is always Transparent (bounding_box.rs:65,71). */
+enum { ORC_SHAPE_SPHERE = 0, ORC_SHAPE_BOX = 1 };
+typedef struct orc_box {
+    double min[3]; /* axes[a].min */
+    double _unused0;
+    uint32_t _unused_kind;
+    uint32_t shape; /* ORC_SHAPE_BOX */
+    double max[3]; /* axes[a].max */
+    double _unused1;
+} orc_box;
 
 /* src/raytracer/hittable.rs:7-13, with the material replaced by the index of
  * the sphere that was hit. */
@@ -133,6 +145,9 @@ double orc_clamp(double lo, double hi, double x);
 
 /* Geometry and materials. */
 int orc_sphere_hit(const orc_sphere* s, const double* ro, const double* rd, double tmin, double tmax, orc_hit* rec);
+/* BoundingBox::hit, bounding_box.rs:50-76, as written: only axes 0 and 1 are looked at, and a plane's distance is
+ * `min - origin / direction`.  Sets t and p of rec only (the reference leaves the other fields as they were). */
+int orc_box_hit(const orc_box* b, const double* ro, const double* rd, double tmin, double tmax, orc_hit* rec);
 int orc_list_hit(const orc_sphere* s, size_t n, const double* ro, const double* rd, double tmin, double tmax, orc_hit* rec);
 int orc_scatter(const orc_sphere* s, const double* rd, const orc_hit* rec, orc_rng* rng, double* attenuation,
                 double* so, double* sd);

@@ -57,14 +57,14 @@ class Sphere(C.Structure):
         ("center", D3),
         ("radius", C.c_double),
         ("kind", C.c_uint32),
-        ("_pad", C.c_uint32),
+        ("shape", C.c_uint32),
         ("albedo", D3),
         ("fuzz_or_ior", C.c_double),
     ]
 
 
 SPHERE_DTYPE = np.dtype(
-    [("center", "<f8", 3), ("radius", "<f8"), ("kind", "<u4"), ("_pad", "<u4"), ("albedo", "<f8", 3),
+    [("center", "<f8", 3), ("radius", "<f8"), ("kind", "<u4"), ("shape", "<u4"), ("albedo", "<f8", 3),
      ("fuzz_or_ior", "<f8")]
 )
 assert SPHERE_DTYPE.itemsize == C.sizeof(Sphere) == 72
@@ -148,6 +148,7 @@ def lib():
     L.orc_clamp.argtypes = [C.c_double] * 3
     L.orc_sphere_hit.argtypes = [P(Sphere), dp, dp, C.c_double, C.c_double, P(Hit)]
     L.orc_list_hit.argtypes = [P(Sphere), C.c_size_t, dp, dp, C.c_double, C.c_double, P(Hit)]
+    L.orc_box_hit.argtypes = [C.c_void_p, dp, dp, C.c_double, C.c_double, P(Hit)]
     L.orc_scatter.argtypes = [P(Sphere), dp, P(Hit), P(Rng), dp, dp, dp]
     L.orc_reflectance.restype = C.c_double
     L.orc_reflectance.argtypes = [C.c_double, C.c_double]
@@ -220,6 +221,25 @@ def make_sphere(center, radius, kind, albedo=(0.0, 0.0, 0.0), fuzz_or_ior=0.0):
     s.kind = kind
     s.albedo = v3(*albedo)
     s.fuzz_or_ior = min(float(fuzz_or_ior), 1.0) if kind == MAT_METAL else float(fuzz_or_ior)
+    return s
+
+
+class Box(C.Structure):
+    """orc_box: a BoundingBox record in an orc_sphere's place."""
+    _fields_ = [("min", D3), ("_unused0", C.c_double), ("_unused_kind", C.c_uint32), ("shape", C.c_uint32),
+                ("max", D3), ("_unused1", C.c_double)]
+
+
+assert C.sizeof(Box) == C.sizeof(Sphere)
+SHAPE_SPHERE, SHAPE_BOX = 0, 1
+
+
+def make_box(x_min, x_max, y_min, y_max, z_min, z_max):
+    """BoundingBox::new_xyz (bounding_box.rs:20-28) as a list record (returned as a Sphere so it can sit in a Sphere array)."""
+    s = Sphere()
+    s.center = v3(x_min, y_min, z_min)
+    s.albedo = v3(x_max, y_max, z_max)
+    s.shape = SHAPE_BOX
     return s
 
 

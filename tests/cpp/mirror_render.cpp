@@ -26,6 +26,7 @@ int main(int argc, char** argv) {
     world.add(std::make_shared<Sphere>(Point3(1.0, 0.0, -1.0), 0.5, std::make_shared<Metal>(Color3(0.8, 0.6, 0.2), 3.0))); // fuzz clamps to 1
     world.add(std::make_shared<Sphere>(Point3(0.0, 1.2, -1.5), -2.0, std::make_shared<DefaultMaterial>()));              // radius clamps to 0
     world.add(std::make_shared<Sphere>(Point3(0.6, -0.3, -0.7), 0.15, std::make_shared<Transparent>()));
+    world.add(std::make_shared<BoundingBox>(0.3, 0.6, 0.2, 0.9, -1.0, 1.0)); // bounding_box.rs: new_xyz
 
     Camera cam = Camera::create();
     cam.aspect_ratio = 16.0 / 9.0;

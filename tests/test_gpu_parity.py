@@ -198,7 +198,7 @@ def test_f32_scan_variants_agree(dray, gpu):
 def soup(rng, n, box, r_lo, r_hi, extra=()):
     """Random overlapping spheres of every material in [-box, box]^3, plus `extra` (centre, radius) spheres."""
     sp = np.zeros(n + len(extra), dtype=np.dtype(
-        [("center", "<f8", 3), ("radius", "<f8"), ("kind", "<u4"), ("_pad", "<u4"), ("albedo", "<f8", 3),
+        [("center", "<f8", 3), ("radius", "<f8"), ("kind", "<u4"), ("shape", "<u4"), ("albedo", "<f8", 3),
          ("fuzz_or_ior", "<f8")]))
     sp["center"][:n] = rng.uniform(-box, box, size=(n, 3))
     sp["radius"][:n] = rng.uniform(r_lo, r_hi, size=n)
@@ -555,6 +555,7 @@ def test_cpp_mirror_matches_python_binding(dray, gpu, oracle, tmp_path):
     world.add(dray.Sphere((1.0, 0.0, -1.0), 0.5, dray.Metal((0.8, 0.6, 0.2), 3.0)))
     world.add(dray.Sphere((0.0, 1.2, -1.5), -2.0, dray.DefaultMaterial()))
     world.add(dray.Sphere((0.6, -0.3, -0.7), 0.15, dray.Transparent()))
+    world.add(dray.BoundingBox.new_xyz(0.3, 0.6, 0.2, 0.9, -1.0, 1.0))
     cam = dray.Camera.new()
     cam.aspect_ratio, cam.image_width, cam.samples_per_pixel, cam.max_depth = 16.0 / 9.0, 48, 4, 10
     cam.mode, cam.seed = dray.MODE_F64, 21
@@ -564,7 +565,7 @@ def test_cpp_mirror_matches_python_binding(dray, gpu, oracle, tmp_path):
     cam.render(world, None, color, raw, None)
     H = cam.image_height
     w, h, px = read_ppm(ppm)
-    assert (w, h) == (W, H) == (info["width"], info["height"]) and info["spheres"] == 6
+    assert (w, h) == (W, H) == (info["width"], info["height"]) and info["spheres"] == 7
     assert (px == channels(color[:W * H].reshape(H, W)).astype(np.uint8)).all()
     assert (np.fromfile(rawf, dtype=np.float64).reshape(H, W, 3) == raw[:W * H].reshape(H, W, 3)).all()
     assert info["segments"] == cam.last_stats.segments
@@ -756,6 +757,69 @@ def test_transparent_material(dray, gpu, oracle):
     w = dray.HittableList()
     w.add(dray.Sphere((0.0, 0.0, -1.0), 0.5, dray.Transparent()))
     assert dray.flatten_world(w)["kind"][0] == dray._ffi.MAT_TRANSPARENT
+
+
+def test_bounding_box_as_a_hittable(dray, gpu, oracle):
+    """BoundingBox entries in the hittable list (bounding_box.rs:50-76 as written: two axes, `min - origin /
+    direction`, Transparent material).  Boxes at the front, in the middle and at the end of the final scene's list:
+    the f64 kernel equals the oracle bit for bit (both products; closest hit by grid walk and by the scan of the whole
+    list), the path-step entries equal the oracle's byte for byte, the f32 scans agree with each other bit for bit,
+    and the f32 image -- a box hit renders black at once -- is the f64 image to the f32 tolerance."""
+    base = dray.scene_final(1)
+    box = lambda *b: dray.flatten_world(dray.HittableList([dray.BoundingBox.new_xyz(*b)]))
+    spheres = np.concatenate([box(-0.5, 0.5, -0.4, 0.6, -1.0, 1.0), base[:200], box(2.0, 2.4, -1.0, 1.0, 0.0, 0.0), base[200:],
+                              box(-3.0, -2.0, 0.1, 0.3, -9.0, 9.0), box(np.inf, -np.inf, np.inf, -np.inf, np.inf, -np.inf)])
+    assert (spheres["shape"] == 1).sum() == 4
+    cam = dray.camera_final(width=96, spp=6, depth=12)
+    cam.seed = 14
+    ref = None
+    for iterative in (0, 1):
+        cam.mode, cam.flags = dray.MODE_F64, dray.FLAG_ITERATIVE_PRODUCT if iterative else 0
+        ocol, oraw, ocnt, ost = oracle.render(ocam_from(oracle, cam), spheres, seed=14, iterative=iterative, threads=8)
+        for variant in (dray.SCAN_AUTO, dray.SCAN_SCALAR):
+            col, raw, cnt, st = render_gpu(dray, gpu, spheres, cam, variant=variant)
+            assert st.segments == ost.segments and (raw == oraw).all() and (col == ocol).all(), (iterative, variant)
+        if not iterative:
+            ref = (ocol, ost)
+    # the boxes matter: without them the image is another one
+    _, raw_plain, _, _ = oracle.render(ocam_from(oracle, cam), base, seed=14, threads=8)
+    _, raw_boxes, _, _ = oracle.render(ocam_from(oracle, cam), spheres, seed=14, threads=8)
+    assert (raw_plain != raw_boxes).any() and (raw_boxes.sum(-1) == 0).mean() > (raw_plain.sum(-1) == 0).mean()
+    cam.mode, cam.flags = dray.MODE_F32, 0
+    res = [render_gpu(dray, gpu, spheres, cam, variant=v) for v in (dray.SCAN_SCALAR, dray.SCAN_HYBRID, dray.SCAN_GRID)]
+    for r in res[1:]:
+        assert (r[0] == res[0][0]).all() and (r[1] == res[0][1]).all() and r[3].segments == res[0][3].segments
+    d = lsb_diff(res[0][0], ref[0]).max(axis=-1)
+    report("bounding_box_f32_vs_oracle", within_1_lsb=float((d <= 1).mean()), max=int(d.max()),
+           segments_f32=int(res[0][3].segments), segments_f64=int(ref[1].segments))
+    assert (d <= 1).mean() >= 0.99
+    assert res[0][3].segments < ref[1].segments   # one segment per sample a box ends, instead of the depth left
+    # path state: entries that meet a box keep their ray and lose one depth per step
+    cam.mode = dray.MODE_F64
+    H, W = cam.initialize().image_height, cam.image_width
+    rng = np.random.default_rng(6)
+    px = np.stack([rng.integers(0, W, 400), rng.integers(0, H, 400), rng.integers(0, 6, 400)], axis=1).astype(np.int32)
+    e = gpu.camera_rays(cam, px)
+    oe = oracle.camera_ray_entries(ocam_from(oracle, cam), px, seed=14)
+    scene = gpu.DeviceScene(spheres, 0)
+    for step in range(14):
+        gpu.ray_color_iteration(e, scene, cam)
+        oracle.ray_color_iteration(oe, spheres, W, seed=14)
+        assert e.tobytes() == oe.tobytes(), step
+    scene.close()
+    # the three-sphere camera sits at the origin, where a box's plane distances do not depend on the ray at all
+    three = np.concatenate([dray.scene_three_spheres(), box(0.3, 0.6, 0.2, 0.9, -1.0, 1.0)])
+    cam3 = dray.camera_three_spheres(width=80, spp=4, depth=8)
+    cam3.mode = dray.MODE_F64
+    col, raw, cnt, st = render_gpu(dray, gpu, three, cam3, seed=2)
+    ocol, oraw, _, ost = oracle.render(ocam_from(oracle, cam3), three, seed=2, threads=4)
+    assert st.segments == ost.segments and (raw == oraw).all() and (col == ocol).all()
+    # an unknown shape is refused
+    bad = spheres.copy()
+    bad["shape"][5] = 2
+    with pytest.raises(dray.DrayError) as err:
+        render_gpu(dray, gpu, bad, cam)
+    assert err.value.status == dray._ffi.ERR_UNSUPPORTED
 
 
 def test_render_over_several_devices_equals_one(dray, gpu):

@@ -391,3 +391,71 @@ def test_transparent_hands_the_ray_back(oracle):
         assert (raw[H // 2, W // 2] == 0.0).all() and (col[H // 2, W // 2] & 0xFFFFFF) == 0
         _, raw2, _, st2 = oracle.render(cam, solid, seed=3, iterative=iterative)
         assert raw2[H // 2, W // 2].sum() > 0 and st.segments != st2.segments
+
+
+def test_bounding_box_hit_as_written(L):
+    """BoundingBox::hit (bounding_box.rs:50-76) is restated as written, quirks included; each value below follows
+    from the cited lines by hand."""
+    box = O.make_box(1.0, 2.0, -1.0, 1.0, -3.0, 3.0)
+    rec = O.Hit()
+    hit = lambda o, d, tmin=0.001, tmax=INF: L.orc_box_hit(C.byref(box), O.v3(*o), O.v3(*d), tmin, tmax, C.byref(rec))
+    # straight at the box along x: axis 0 gives 1 - 0/1 = 1 and 2 - 0/1 = 2; axis 1 has direction 0 and is skipped (:54)
+    assert hit((0, 0, 0), (1, 0, 0)) and rec.t == 1.0 and tuple(rec.p) == (1.0, 0.0, 0.0)
+    # :55-56 compute `min - origin / direction`, not `(min - origin) / direction`: from x = 2 with direction 2 the
+    # planes are "at" 1 - 2/2 = 0 and 2 - 2/2 = 1; 0 is not inside (0.001, inf), so t_max = 1 is taken (:68-72) and
+    # the hit point lies at x = 4, outside the box
+    assert hit((2, 0, 0), (2, 0, 0)) and rec.t == 1.0 and tuple(rec.p) == (4.0, 0.0, 0.0)
+    # :53 loops over axes 0 and 1 only: z never matters -- a ray far outside the z interval still hits ...
+    assert hit((0, 0, 100), (1, 0, 0)) and rec.t == 1.0 and tuple(rec.p) == (1.0, 0.0, 100.0)
+    # ... and a ray along z, whose x and y directions are both 0, keeps t_min = -inf, t_max = +inf: neither is
+    # inside the interval, so it misses even when it runs through the middle of the box
+    assert not hit((1.5, 0, -10), (0, 0, 1))
+    # both axes: max of the entries, min of the exits.  o = (0, -4), d = (1, 2): x planes 1, 2; y planes -1 + 2 = 1, 1 + 2 = 3
+    assert hit((0, -4, 0), (1, 2, 0)) and rec.t == 1.0
+    # y planes at -1 - (-12/2) = 5 and 7, x planes at 1 and 2: t_max = 2 < t_min = 5, a miss (:61)
+    assert not hit((0, -12, 0), (1, 2, 0))
+    # the interval is open (interval.rs:28-30): t_min == tmin falls through to t_max; an upper bound at or below t_min
+    # leaves nothing (t_max >= t_min is no nearer)
+    assert hit((0, 0, 0), (1, 0, 0), tmin=1.0) and rec.t == 2.0
+    assert not hit((0, 0, 0), (1, 0, 0), tmax=1.0)
+    assert hit((0, 0, 0), (1, 0, 0), tmax=1.5) and rec.t == 1.0
+    # only t and p are written: normal and front_face keep what the record held (:63-66)
+    rec.normal = O.v3(7.0, 8.0, 9.0)
+    rec.front_face = 1
+    assert hit((0, 0, 0), (1, 0, 0)) and tuple(rec.normal) == (7.0, 8.0, 9.0) and rec.front_face == 1
+    # BoundingBox::default is three EMPTY intervals (+inf, -inf): t_min = -inf, t_max = +inf, nothing inside the interval
+    empty = O.make_box(INF, -INF, INF, -INF, INF, -INF)
+    assert not L.orc_box_hit(C.byref(empty), O.v3(0, 0, 0), O.v3(1, 1, 1), 0.001, INF, C.byref(rec))
+    # a NaN direction is "not zero" (:54) and f64::max / f64::min drop the NaN operand: the bounds stay infinite
+    assert not hit((0, 0, 0), (float("nan"), 0, 0))
+
+
+def test_bounding_box_in_a_list_and_its_material(L, oracle):
+    """A box takes part in HittableList::hit like any hittable (hittable_list.rs:65-70): smallest t, on equal t the
+    entry inserted first.  Its material is Transparent (bounding_box.rs:65,71): the incoming ray comes back unchanged,
+    meets the box again at every depth left, and the sample ends black."""
+    box = O.make_box(1.0, 2.0, -1.0, 1.0, -3.0, 3.0)
+    near = O.make_sphere((0.5, 0, 0), 0.25, O.MAT_LAMBERTIAN, (1, 0, 0))   # hit at t = 0.25
+    same = O.make_sphere((1.5, 0, 0), 0.5, O.MAT_LAMBERTIAN, (0, 1, 0))    # hit at t = 1.0, the box's distance
+    rec = O.Hit()
+    o, d = O.v3(0, 0, 0), O.v3(1, 0, 0)
+    assert L.orc_list_hit((O.Sphere * 2)(box, near), 2, o, d, 0.001, INF, C.byref(rec)) and rec.index == 1 and rec.t == 0.25
+    assert L.orc_list_hit((O.Sphere * 2)(box, same), 2, o, d, 0.001, INF, C.byref(rec)) and rec.index == 0 and rec.t == 1.0
+    assert L.orc_list_hit((O.Sphere * 2)(same, box), 2, o, d, 0.001, INF, C.byref(rec)) and rec.index == 0
+    # the sphere's normal stays in the record when the box behind it in the list is hit closer (the reference's
+    # temp_rec is shared by the whole scan, hittable_list.rs:61-69)
+    far = O.make_sphere((5, 0, 0), 0.5, O.MAT_LAMBERTIAN, (0, 0, 1))
+    assert L.orc_list_hit((O.Sphere * 2)(far, box), 2, o, d, 0.001, INF, C.byref(rec)) and rec.index == 1
+    assert tuple(rec.normal) == (-1.0, 0.0, 0.0) and tuple(rec.p) == (1.0, 0.0, 0.0)
+    # whole paths: a box that fills the view makes every sample black after max_depth segments
+    spheres = oracle.scene_three_spheres()
+    arr = np.concatenate([spheres, oracle.spheres_to_numpy((O.Sphere * 1)(O.make_box(-50, 50, -50, 50, -2, -1)), 1)])
+    cam = oracle.camera_three_spheres(width=16, spp=2, depth=5)
+    for iterative in (0, 1):
+        col, raw, cnt, st = oracle.render(cam, arr, seed=4, iterative=iterative)
+        _, raw0, _, st0 = oracle.render(cam, spheres, seed=4, iterative=iterative)
+        assert raw0.sum() > 0
+        # x planes "at" -50 - 0/dx and 50 - 0/dx (the camera is at the origin): every ray is inside from t = -50 to 50,
+        # so t_max = 50 is inside the interval unless a sphere is closer: the sky pixels turn black, spheres stay
+        sky = raw0[0, 0].sum() > 0 and raw[0, 0].sum() == 0
+        assert sky and st.segments > st0.segments

@@ -17,7 +17,7 @@ sys.path.insert(0, ROOT)
 
 
 def short_name(name):
-    m = re.search(r"render_f32_kernel<\(?(?:int\))?(\d)>", name)
+    m = re.search(r"render_f32_kernel<(?:\(int\))?(\d), (?:\(bool\))?(?:false|0)>", name)   # the kernels without boxes
     if m:
         return "render_f32_kernel<%s>" % m.group(1)
     if "render_ref_kernel<double>" in name:
