@@ -24,6 +24,7 @@ ERR_HIP = -5
 ERR_INTERNAL = -6
 ERR_TOO_LARGE = -7
 NOALLOC_MAX_PIXELS = 1048576
+SYNC_UPLOAD_SUMS, SYNC_DOWNLOAD_SUMS = 1, 2
 
 MAT_DEFAULT, MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC, MAT_TRANSPARENT = 0, 1, 2, 3, 4
 MODE_F64, MODE_F32, MODE_F32_PLAIN = 0, 1, 2
@@ -134,7 +135,8 @@ EXPORTS = (
     "dray_camera_initialize", "dray_render", "dray_render_multi", "dray_scene_create", "dray_scene_destroy", "dray_render_device",
     "dray_scene_final", "dray_scene_recipe", "dray_scene_three_spheres", "dray_write_ppm", "dray_camera_rays",
     "dray_path_step", "dray_camera_rays_device", "dray_path_step_device", "dray_grid_inspect",
-    "dray_render_device_noalloc",
+    "dray_render_device_noalloc", "dray_release_cache", "dray_context_create", "dray_context_destroy",
+    "dray_context_set_scene", "dray_context_render", "dray_context_pin", "dray_context_unpin", "dray_context_host_alloc",
 )
 
 _lib = None
@@ -184,6 +186,18 @@ def lib():
     L.dray_render_device.argtypes = [P(CameraPOD), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, P(Opts),
                                      C.c_void_p, P(Stats)]
     L.dray_render_device_noalloc.argtypes = L.dray_render_device.argtypes
+    L.dray_release_cache.restype = None
+    L.dray_release_cache.argtypes = []
+    L.dray_context_create.argtypes = [C.c_void_p, C.c_int32, P(C.c_void_p)]
+    L.dray_context_destroy.restype = None
+    L.dray_context_destroy.argtypes = [C.c_void_p]
+    L.dray_context_set_scene.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    L.dray_context_render.argtypes = [C.c_void_p, P(CameraPOD), C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, P(Opts),
+                                      C.c_uint32, P(Stats)]
+    L.dray_context_pin.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    L.dray_context_host_alloc.argtypes = [C.c_void_p, C.c_size_t, P(C.c_void_p)]
+    L.dray_context_unpin.restype = None
+    L.dray_context_unpin.argtypes = [C.c_void_p]
     L.dray_scene_final.argtypes = [C.c_uint64, C.c_void_p, C.c_size_t]
     L.dray_scene_three_spheres.argtypes = [C.c_void_p, C.c_size_t]
     L.dray_write_ppm.argtypes = [C.c_char_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32]

@@ -51,6 +51,7 @@ namespace {
 thread_local char g_detail[256] = "";
 
 int hip_fail(hipError_t e, const char* what) {
+    (void)hipGetLastError(); // the runtime remembers the error; the next kernel launch's check must not find it
     snprintf(g_detail, sizeof g_detail, "%s: %s", what, hipGetErrorString(e));
     return DRAY_ERR_HIP;
 }
@@ -581,106 +582,143 @@ unsigned long long* noalloc_workspace(int device) {
     return g_noalloc_ptr[device];
 }
 
-int render_device_impl(const dray_camera* cam, dray_scene* scene, uint32_t* d_color, double* d_raw, int32_t* d_count,
-                       size_t buf_len, const dray_opts* opts_in, void* stream_v, dray_stats* stats,
-                       bool noalloc = false) {
-    const auto t_begin = std::chrono::steady_clock::now();
-    if (!camera_ok(cam) || !scene || !d_color) return DRAY_ERR_INVALID_ARG;
-    dray_opts opts;
-    if (opts_in) opts = *opts_in; else dray_opts_default(&opts);
-    if (opts.mode > DRAY_MODE_F32_PLAIN || opts.variant < 0 || opts.variant > DRAY_SCAN_GRID) return DRAY_ERR_INVALID_ARG;
-    if (opts.row_step == 0) opts.row_step = 1;
-    if (opts.row_step < 0 || opts.row_begin < 0) return DRAY_ERR_INVALID_ARG;
-    if (opts.device >= 0 && opts.device != scene->device) return DRAY_ERR_INVALID_ARG;
-
-    dray_camera_derived dv;
-    int rc = dray_camera_initialize(cam, &dv);
-    if (rc) return rc;
-    const int32_t W = cam->image_width, H = dv.image_height;
+// One render on one scene, in the steps its callers need apart: check the arguments (prepare), start the trace
+// kernel, which reads only the scene (begin), then -- once the running sums it adds to are in place -- the kernel that
+// reads and writes the caller's buffers (finish), and, after the work is done, the statistics (collect).  The job holds
+// the scene's lock from prepare to finish: a scene serves one call at a time.
+struct RenderJob {
+    const dray_camera* cam = nullptr;
+    dray_scene* scene = nullptr;
+    dray_opts opts{};
+    bool noalloc = false, empty = false;
+    dray_camera_derived dv{};
     Partition part{};
-    part.row_begin = opts.row_begin;
-    part.row_step = opts.row_step;
-    part.n_rows = opts.row_begin < H ? (H - opts.row_begin + opts.row_step - 1) / opts.row_step : 0;
-    part.compact = (opts.flags & DRAY_FLAG_COMPACT_ROWS) ? 1 : 0;
-    const size_t need = part.compact ? (size_t)part.n_rows * (size_t)W : (size_t)W * (size_t)H;
-    if (buf_len < need) return DRAY_ERR_BUFFER_TOO_SMALL;
-    const bool exact_product = opts.mode != DRAY_MODE_F32 && !(opts.flags & DRAY_FLAG_ITERATIVE_PRODUCT);
-    if (exact_product && cam->max_depth > kExactMaxDepth) return DRAY_ERR_UNSUPPORTED;
-
-    if (stats) {
-        std::memset(stats, 0, sizeof *stats);
-        stats->image_height = H;
-        stats->rows_rendered = part.n_rows;
-        stats->n_spheres = scene->dev.n;
-        stats->n_wide_spheres = opts.mode == DRAY_MODE_F32 ? scene->dev.n_wide : 0;
-    }
-    // camera.rs:217: no samples, no writes
-    if (cam->samples_per_pixel <= 0 || part.n_rows == 0) return DRAY_OK;
-
-    DeviceGuard g(scene->device);
-    if (g.err != hipSuccess) return hip_fail(g.err, "hipSetDevice");
-    hipStream_t stream = (hipStream_t)stream_v;
-    const RngKey key = {(uint32_t)opts.seed, (uint32_t)(opts.seed >> 32), opts.sample_offset};
-
-    // one call at a time per scene (see dray_scene)
-    std::lock_guard<std::mutex> lock(scene->mu);
-    if (scene->has_last && scene->last_stream != stream) HIP_TRY(hipStreamWaitEvent(stream, scene->ev[2], 0));
-    scene->last_stream = stream;
-
-    // the counters and the f32 kernel's sums: the scene's own buffers (grown when a frame needs more), or the
-    // library's static array for the entry point that may not allocate
-    DeviceCounters* d_counters = scene->d_counters;
+    int32_t W = 0, H = 0;
+    hipStream_t stream = nullptr;
+    DeviceCounters* d_counters = nullptr;
     unsigned long long* d_accum = nullptr;
-    if (noalloc) {
-        if ((size_t)part.n_rows * (size_t)W > kNoAllocMaxPixels) {
-            snprintf(g_detail, sizeof g_detail, "%d rows x %d pixels exceed the %zu pixels of the allocation-free workspace",
-                     part.n_rows, W, kNoAllocMaxPixels);
-            return DRAY_ERR_TOO_LARGE;
-        }
-        unsigned long long* ws = noalloc_workspace(scene->device);
-        if (!ws) return DRAY_ERR_HIP;
-        d_counters = (DeviceCounters*)ws;
-        d_accum = ws + kNoAllocCounterWords;
-    }
-    static_assert(sizeof(DeviceCounters) <= kNoAllocCounterWords * sizeof(unsigned long long), "counters outgrew their slot");
+    F32Plan plan{};
+    std::unique_lock<std::mutex> lock;
+    std::chrono::steady_clock::time_point t_begin;
 
-    HIP_TRY(hipMemsetAsync(d_counters, 0, sizeof(DeviceCounters), stream));
-    if (opts.mode == DRAY_MODE_F32) {
-        const CamDev<float> c = make_cam<float>(*cam, dv);
-        F32Plan plan = plan_render_f32(c, part, opts.pixels_per_pool, opts.variant, scene->dev, scene->device);
-        plan.no_refill = (opts.flags & DRAY_FLAG_NO_REFILL) ? 1 : 0;
-        if (opts.variant == DRAY_SCAN_HYBRID && plan.scan != DRAY_SCAN_HYBRID) return DRAY_ERR_UNSUPPORTED; // table beyond the LDS staging limit
-        if (!noalloc) {
-            if (plan.accum_words > scene->accum_capacity) {
-                if (scene->d_accum) HIP_TRY(hipFree(scene->d_accum)); // waits for the device: no earlier call still reads it
-                scene->d_accum = nullptr;
-                scene->accum_capacity = 0;
-                HIP_TRY(hipMalloc((void**)&scene->d_accum, plan.accum_words * sizeof(unsigned long long)));
-                scene->accum_capacity = plan.accum_words;
+    // Returns a status; `empty` says that there is nothing to render (camera.rs:217: no samples, no writes).
+    int prepare(const dray_camera* cam_in, dray_scene* scene_in, bool have_color, size_t buf_len, const dray_opts* opts_in,
+                void* stream_v, bool noalloc_in, dray_stats* stats) {
+        t_begin = std::chrono::steady_clock::now();
+        cam = cam_in; scene = scene_in; noalloc = noalloc_in;
+        if (!camera_ok(cam) || !scene || !have_color) return DRAY_ERR_INVALID_ARG;
+        if (opts_in) opts = *opts_in; else dray_opts_default(&opts);
+        if (opts.mode > DRAY_MODE_F32_PLAIN || opts.variant < 0 || opts.variant > DRAY_SCAN_GRID) return DRAY_ERR_INVALID_ARG;
+        if (opts.row_step == 0) opts.row_step = 1;
+        if (opts.row_step < 0 || opts.row_begin < 0) return DRAY_ERR_INVALID_ARG;
+        if (opts.device >= 0 && opts.device != scene->device) return DRAY_ERR_INVALID_ARG;
+        int rc = dray_camera_initialize(cam, &dv);
+        if (rc) return rc;
+        W = cam->image_width; H = dv.image_height;
+        part.row_begin = opts.row_begin;
+        part.row_step = opts.row_step;
+        part.n_rows = opts.row_begin < H ? (H - opts.row_begin + opts.row_step - 1) / opts.row_step : 0;
+        part.compact = (opts.flags & DRAY_FLAG_COMPACT_ROWS) ? 1 : 0;
+        const size_t need = part.compact ? (size_t)part.n_rows * (size_t)W : (size_t)W * (size_t)H;
+        if (buf_len < need) return DRAY_ERR_BUFFER_TOO_SMALL;
+        const bool exact_product = opts.mode != DRAY_MODE_F32 && !(opts.flags & DRAY_FLAG_ITERATIVE_PRODUCT);
+        if (exact_product && cam->max_depth > kExactMaxDepth) return DRAY_ERR_UNSUPPORTED;
+        if (stats) {
+            std::memset(stats, 0, sizeof *stats);
+            stats->image_height = H;
+            stats->rows_rendered = part.n_rows;
+            stats->n_spheres = scene->dev.n;
+            stats->n_wide_spheres = opts.mode == DRAY_MODE_F32 ? scene->dev.n_wide : 0;
+        }
+        empty = cam->samples_per_pixel <= 0 || part.n_rows == 0;
+        stream = (hipStream_t)stream_v;
+        return DRAY_OK;
+    }
+
+    // Clears the workspace and, in the f32 mode, enqueues the trace kernel.
+    int begin() {
+        DeviceGuard g(scene->device);
+        if (g.err != hipSuccess) return hip_fail(g.err, "hipSetDevice");
+        lock = std::unique_lock<std::mutex>(scene->mu); // one call at a time per scene (see dray_scene)
+        if (scene->has_last && scene->last_stream != stream) HIP_TRY(hipStreamWaitEvent(stream, scene->ev[2], 0));
+        scene->last_stream = stream;
+
+        // the counters and the f32 kernel's sums: the scene's own buffers (grown when a frame needs more), or the
+        // library's static array for the entry point that may not allocate
+        d_counters = scene->d_counters;
+        if (noalloc) {
+            if ((size_t)part.n_rows * (size_t)W > kNoAllocMaxPixels) {
+                snprintf(g_detail, sizeof g_detail, "%d rows x %d pixels exceed the %zu pixels of the allocation-free workspace",
+                         part.n_rows, W, kNoAllocMaxPixels);
+                return DRAY_ERR_TOO_LARGE;
             }
-            d_accum = scene->d_accum;
+            unsigned long long* ws = noalloc_workspace(scene->device);
+            if (!ws) return DRAY_ERR_HIP;
+            d_counters = (DeviceCounters*)ws;
+            d_accum = ws + kNoAllocCounterWords;
         }
-        HIP_TRY(hipMemsetAsync(d_accum, 0, plan.accum_words * sizeof(unsigned long long), stream));
-        HIP_TRY(hipEventRecord(scene->ev[0], stream));
-        if (cam->max_depth > 0) // camera.rs:265: with no depth every sample is black and no ray is traced
-            HIP_TRY(launch_render_f32(c, scene->dev, part, key, plan, d_accum, d_counters, stream));
-        HIP_TRY(hipEventRecord(scene->ev[1], stream));
-        HIP_TRY(launch_resolve_f32(c, part, d_accum, d_color, d_raw, d_count, stream));
-        HIP_TRY(hipEventRecord(scene->ev[2], stream));
-    } else {
-        HIP_TRY(hipEventRecord(scene->ev[0], stream));
-        if (opts.mode == DRAY_MODE_F64)
-            HIP_TRY(launch_render_ref_f64(make_cam<double>(*cam, dv), scene->dev, part, key, opts.flags,
-                                          opts.variant != DRAY_SCAN_SCALAR, d_color, d_raw, d_count, d_counters, stream));
-        else
-            HIP_TRY(launch_render_ref_f32(make_cam<float>(*cam, dv), scene->dev, part, key, opts.flags, d_color, d_raw,
-                                          d_count, d_counters, stream));
-        HIP_TRY(hipEventRecord(scene->ev[1], stream));
-        HIP_TRY(hipEventRecord(scene->ev[2], stream));
-    }
-    scene->has_last = true;
+        static_assert(sizeof(DeviceCounters) <= kNoAllocCounterWords * sizeof(unsigned long long), "counters outgrew their slot");
 
-    if (stats) {
+        HIP_TRY(hipMemsetAsync(d_counters, 0, sizeof(DeviceCounters), stream));
+        if (opts.mode == DRAY_MODE_F32) {
+            const CamDev<float> c = make_cam<float>(*cam, dv);
+            plan = plan_render_f32(c, part, opts.pixels_per_pool, opts.variant, scene->dev, scene->device);
+            plan.no_refill = (opts.flags & DRAY_FLAG_NO_REFILL) ? 1 : 0;
+            if (opts.variant == DRAY_SCAN_HYBRID && plan.scan != DRAY_SCAN_HYBRID) return DRAY_ERR_UNSUPPORTED; // table beyond the LDS staging limit
+            if (!noalloc) {
+                if (plan.accum_words > scene->accum_capacity) {
+                    if (scene->d_accum) HIP_TRY(hipFree(scene->d_accum)); // waits for the device: no earlier call still reads it
+                    scene->d_accum = nullptr;
+                    scene->accum_capacity = 0;
+                    HIP_TRY(hipMalloc((void**)&scene->d_accum, plan.accum_words * sizeof(unsigned long long)));
+                    scene->accum_capacity = plan.accum_words;
+                }
+                d_accum = scene->d_accum;
+            }
+            HIP_TRY(hipMemsetAsync(d_accum, 0, plan.accum_words * sizeof(unsigned long long), stream));
+            HIP_TRY(hipEventRecord(scene->ev[0], stream));
+            const RngKey key = {(uint32_t)opts.seed, (uint32_t)(opts.seed >> 32), opts.sample_offset};
+            if (cam->max_depth > 0) // camera.rs:265: with no depth every sample is black and no ray is traced
+                HIP_TRY(launch_render_f32(c, scene->dev, part, key, plan, d_accum, d_counters, stream));
+            HIP_TRY(hipEventRecord(scene->ev[1], stream));
+        }
+        return DRAY_OK;
+    }
+
+    // Enqueues the kernel that reads and writes the caller's buffers (after `inputs_ready`, if given: an event recorded
+    // on another stream once the buffers hold what the render adds to), then lets go of the scene.
+    int finish(uint32_t* d_color, double* d_raw, int32_t* d_count, hipEvent_t inputs_ready) {
+        DeviceGuard g(scene->device);
+        if (g.err != hipSuccess) return hip_fail(g.err, "hipSetDevice");
+        const RngKey key = {(uint32_t)opts.seed, (uint32_t)(opts.seed >> 32), opts.sample_offset};
+        if (inputs_ready) HIP_TRY(hipStreamWaitEvent(stream, inputs_ready, 0));
+        if (opts.mode == DRAY_MODE_F32) {
+            HIP_TRY(launch_resolve_f32(make_cam<float>(*cam, dv), part, d_accum, d_color, d_raw, d_count, stream));
+            HIP_TRY(hipEventRecord(scene->ev[2], stream));
+        } else {
+            HIP_TRY(hipEventRecord(scene->ev[0], stream));
+            if (opts.mode == DRAY_MODE_F64)
+                HIP_TRY(launch_render_ref_f64(make_cam<double>(*cam, dv), scene->dev, part, key, opts.flags,
+                                              opts.variant != DRAY_SCAN_SCALAR, d_color, d_raw, d_count, d_counters, stream));
+            else
+                HIP_TRY(launch_render_ref_f32(make_cam<float>(*cam, dv), scene->dev, part, key, opts.flags, d_color, d_raw,
+                                              d_count, d_counters, stream));
+            HIP_TRY(hipEventRecord(scene->ev[1], stream));
+            HIP_TRY(hipEventRecord(scene->ev[2], stream));
+        }
+        scene->has_last = true;
+        lock.unlock();
+        return DRAY_OK;
+    }
+
+    void abandon() { // a step failed: let go of the scene
+        if (lock.owns_lock()) lock.unlock();
+    }
+
+    // Waits for the job and fills in what the device counted.  Call before the scene takes its next job.
+    int collect(dray_stats* stats) {
+        DeviceGuard g(scene->device);
+        if (g.err != hipSuccess) return hip_fail(g.err, "hipSetDevice");
         HIP_TRY(hipEventSynchronize(scene->ev[2]));
         DeviceCounters hc{};
         HIP_TRY(hipMemcpy(&hc, d_counters, sizeof hc, hipMemcpyDeviceToHost));
@@ -695,8 +733,21 @@ int render_device_impl(const dray_camera* cam, dray_scene* scene, uint32_t* d_co
         stats->kernel_ms = k_ms;
         stats->resolve_ms = r_ms;
         stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+        return DRAY_OK;
     }
-    return DRAY_OK;
+};
+
+int render_device_impl(const dray_camera* cam, dray_scene* scene, uint32_t* d_color, double* d_raw, int32_t* d_count,
+                       size_t buf_len, const dray_opts* opts_in, void* stream_v, dray_stats* stats,
+                       bool noalloc = false) {
+    RenderJob job;
+    int rc = job.prepare(cam, scene, d_color != nullptr, buf_len, opts_in, stream_v, noalloc, stats);
+    if (rc || job.empty) return rc;
+    if ((rc = job.begin()) || (rc = job.finish(d_color, d_raw, d_count, nullptr))) {
+        job.abandon();
+        return rc;
+    }
+    return stats ? job.collect(stats) : DRAY_OK;
 }
 
 int render_host_impl(const dray_camera* cam, const dray_sphere* spheres, size_t n, uint32_t* color, double* raw,
@@ -757,137 +808,340 @@ int render_host_impl(const dray_camera* cam, const dray_sphere* spheres, size_t 
     return rc;
 }
 
-// One device's share of a frame rendered for host buffers: scanlines `share`, `share + n_shares`, ... on `device`,
-// uploaded from and written back to those rows of the caller's buffers (strided copies).
-int render_share(const dray_camera* cam, const dray_sphere* spheres, size_t n, uint32_t* color, double* raw, int32_t* count,
-                 const dray_opts& base, int32_t device, int32_t share, int32_t n_shares, size_t W, size_t H,
-                 dray_stats* stats) {
-    const size_t n_rows = (size_t)share < H ? (H - share + n_shares - 1) / n_shares : 0;
-    std::memset(stats, 0, sizeof *stats);
-    if (n_rows == 0) return DRAY_OK;
+int resolve_device(const dray_opts& opts, int* device) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return DRAY_ERR_NO_DEVICE;
+    *device = opts.device;
+    if (*device < 0) HIP_TRY(hipGetDevice(device));
+    if (*device >= ndev) return DRAY_ERR_INVALID_ARG;
+    return DRAY_OK;
+}
+
+} // namespace
+
+// ---------------------------------------------------------------------------------------------------------------
+// A render context: everything the one-call route (host buffers in, host buffers out) would otherwise set up and tear
+// down per call, kept between calls -- per share of the frame a scene (sphere tables, grid, workspace) on its device,
+// the device-side colour / sum / count slabs, two streams and a pinned staging block.  Share k of G renders scanlines
+// k, k + G, ... (whole scene replicated), as dray_render_multi describes.
+struct CtxShare {
+    int32_t device = 0;
     dray_scene* scene = nullptr;
-    int rc = scene_create_impl(spheres, n, device, &scene);
-    if (rc) return rc;
-    DeviceGuard g(scene->device);
+    hipStream_t compute = nullptr, copy = nullptr;
+    hipEvent_t uploaded = nullptr;
     uint32_t* d_color = nullptr;
     double* d_raw = nullptr;
     int32_t* d_count = nullptr;
-    auto cleanup = [&]() {
-        (void)hipFree(d_color); (void)hipFree(d_raw); (void)hipFree(d_count);
-        scene_free(scene);
-    };
-    auto fail = [&](hipError_t e, const char* what) { int r = hip_fail(e, what); cleanup(); return r; };
-    const size_t slab = n_rows * W;
-    // image row share + k * n_shares <-> slab row k.  The rows are gathered into (scattered from) one contiguous
-    // staging block on the host and cross the bus in one copy: a strided hipMemcpy2D from pageable memory goes row
-    // by row (675 rows x 5 copies took 27 ms, as long as the render itself).
-    std::vector<char> stage;
-    auto rows = [&](void* dev, void* host, size_t elem, hipMemcpyKind kind) {
-        char* h = (char*)host + (size_t)share * W * elem;
-        const size_t row = W * elem, host_pitch = (size_t)n_shares * row;
-        if (n_shares == 1) return hipMemcpy(kind == hipMemcpyHostToDevice ? dev : (void*)h,
-                                            kind == hipMemcpyHostToDevice ? (const void*)h : dev, n_rows * row, kind);
-        stage.resize(n_rows * row);
-        if (kind == hipMemcpyHostToDevice) {
-            for (size_t k = 0; k < n_rows; ++k) std::memcpy(stage.data() + k * row, h + k * host_pitch, row);
-            return hipMemcpy(dev, stage.data(), n_rows * row, kind);
-        }
-        const hipError_t e = hipMemcpy(stage.data(), dev, n_rows * row, kind);
-        if (e == hipSuccess)
-            for (size_t k = 0; k < n_rows; ++k) std::memcpy(h + k * host_pitch, stage.data() + k * row, row);
-        return e;
-    };
-    hipError_t e;
-    if ((e = hipMalloc((void**)&d_color, slab * sizeof(uint32_t))) != hipSuccess) return fail(e, "hipMalloc color");
-    if (raw) {
-        if ((e = hipMalloc((void**)&d_raw, slab * 3 * sizeof(double))) != hipSuccess) return fail(e, "hipMalloc raw");
-        if ((e = rows(d_raw, raw, 3 * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "upload raw");
+    size_t cap = 0; // pixels the three slabs hold
+    char* stage = nullptr; // pinned host block: colour slab, sums slab, count slab
+    size_t stage_bytes = 0;
+    RenderJob job;
+    dray_stats stats{};
+    bool active = false;
+};
+
+struct dray_context {
+    std::mutex mu; // one call at a time
+    std::vector<CtxShare> shares;
+    std::vector<dray_sphere> spheres; // the list the shares' scenes were built from
+    bool have_scene = false;
+    struct Pin { char* p; size_t bytes; bool owned; };
+    // host ranges the copy engines reach directly: registered with the HIP runtime (dray_context_pin) or allocated
+    // pinned by the context (dray_context_host_alloc, `owned`)
+    std::vector<Pin> pins;
+    int32_t res_W = 0, res_H = 0; // frame whose running sums the device slabs hold (0: none)
+    bool res_raw = false, res_count = false;
+};
+
+namespace {
+
+void context_free(dray_context* c) {
+    if (!c) return;
+    for (CtxShare& sh : c->shares) {
+        DeviceGuard g(sh.device);
+        if (sh.compute) (void)hipStreamSynchronize(sh.compute);
+        if (sh.copy) (void)hipStreamSynchronize(sh.copy);
+        (void)hipFree(sh.d_color); (void)hipFree(sh.d_raw); (void)hipFree(sh.d_count);
+        if (sh.stage) (void)hipHostFree(sh.stage);
+        if (sh.uploaded) (void)hipEventDestroy(sh.uploaded);
+        if (sh.compute) (void)hipStreamDestroy(sh.compute);
+        if (sh.copy) (void)hipStreamDestroy(sh.copy);
+        scene_free(sh.scene);
     }
-    if (count) {
-        if ((e = hipMalloc((void**)&d_count, slab * sizeof(int32_t))) != hipSuccess) return fail(e, "hipMalloc count");
-        if ((e = rows(d_count, count, sizeof(int32_t), hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "upload count");
+    for (auto& pin : c->pins) {
+        if (pin.owned) (void)hipHostFree(pin.p);
+        else (void)hipHostUnregister(pin.p);
     }
-    dray_opts opts = base;
-    opts.device = scene->device;
-    opts.row_begin = share;
-    opts.row_step = n_shares;
-    opts.flags |= DRAY_FLAG_COMPACT_ROWS;
-    rc = render_device_impl(cam, scene, d_color, d_raw, d_count, slab, &opts, nullptr, stats);
-    if (rc == DRAY_OK) {
-        if ((e = hipDeviceSynchronize()) != hipSuccess) return fail(e, "hipDeviceSynchronize");
-        if ((e = rows(d_color, color, sizeof(uint32_t), hipMemcpyDeviceToHost)) != hipSuccess) return fail(e, "download color");
-        if (raw && (e = rows(d_raw, raw, 3 * sizeof(double), hipMemcpyDeviceToHost)) != hipSuccess) return fail(e, "download raw");
-        if (count && (e = rows(d_count, count, sizeof(int32_t), hipMemcpyDeviceToHost)) != hipSuccess) return fail(e, "download count");
-    }
-    cleanup();
-    return rc;
+    delete c;
 }
 
-// Camera::render over several GPUs from one process: one host thread per share.
-int render_multi_impl(const dray_camera* cam, const dray_sphere* spheres, size_t n, uint32_t* color, double* raw,
-                      int32_t* count, size_t buf_len, const dray_opts* opts_in, const int32_t* devices, int32_t n_devices,
-                      dray_stats* stats) {
+int context_create_impl(const int32_t* devices, int32_t n_devices, dray_context** out) {
+    if (!out) return DRAY_ERR_INVALID_ARG;
+    *out = nullptr;
+    int visible = 0;
+    if (hipGetDeviceCount(&visible) != hipSuccess || visible < 1) return DRAY_ERR_NO_DEVICE;
+    if (n_devices <= 0) { // every visible GPU
+        n_devices = visible;
+        devices = nullptr;
+    }
+    if (n_devices > 64) return DRAY_ERR_INVALID_ARG;
+    dray_context* c = new (std::nothrow) dray_context();
+    if (!c) return DRAY_ERR_INTERNAL;
+    c->shares.resize((size_t)n_devices);
+    for (int32_t k = 0; k < n_devices; ++k) {
+        const int32_t d = devices ? devices[k] : k;
+        if (d < 0 || d >= visible) {
+            context_free(c);
+            return DRAY_ERR_INVALID_ARG;
+        }
+        CtxShare& sh = c->shares[(size_t)k];
+        sh.device = d;
+        DeviceGuard g(d);
+        hipError_t e = g.err;
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&sh.compute, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&sh.copy, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&sh.uploaded, hipEventDisableTiming);
+        if (e != hipSuccess) {
+            const int rc = hip_fail(e, "context streams");
+            context_free(c);
+            return rc;
+        }
+    }
+    *out = c;
+    return DRAY_OK;
+}
+
+// Builds the shares' scenes from the list, unless they were built from this very list already.
+int context_set_scene_locked(dray_context* c, const dray_sphere* spheres, size_t n) {
+    if (!spheres && n) return DRAY_ERR_INVALID_ARG;
+    if (c->have_scene && c->spheres.size() == n && (n == 0 || std::memcmp(c->spheres.data(), spheres, n * sizeof *spheres) == 0))
+        return DRAY_OK;
+    for (size_t k = 0; k < n; ++k)
+        if (!entry_ok(spheres[k])) return DRAY_ERR_UNSUPPORTED;
+    c->have_scene = false;
+    for (CtxShare& sh : c->shares) {
+        if (sh.compute) {
+            DeviceGuard g(sh.device);
+            (void)hipStreamSynchronize(sh.compute);
+        }
+        scene_free(sh.scene);
+        sh.scene = nullptr;
+    }
+    for (CtxShare& sh : c->shares) {
+        const int rc = scene_create_impl(spheres, n, sh.device, &sh.scene);
+        if (rc) return rc;
+    }
+    c->spheres.assign(spheres, spheres + n);
+    c->have_scene = true;
+    c->res_W = c->res_H = 0; // the slabs' sums belong to renders of the previous list: not to be carried over silently
+    return DRAY_OK;
+}
+
+// Is [p, p + bytes) covered by the registered ranges (page-aligned, disjoint, possibly adjacent)?
+bool pinned(const dray_context* c, const void* p, size_t bytes) {
+    const char* at = (const char*)p;
+    const char* end = at + bytes;
+    for (bool moved = true; at < end && moved;) {
+        moved = false;
+        for (const auto& pin : c->pins)
+            if (at >= pin.p && at < pin.p + pin.bytes) {
+                at = pin.p + pin.bytes;
+                moved = true;
+                break;
+            }
+    }
+    return at >= end;
+}
+
+// Registers the pages of [host, host + bytes) that no earlier registration holds (two buffers of the caller may meet
+// inside one page, and the runtime refuses to register a page twice).
+int context_pin_locked(dray_context* c, void* host, size_t bytes) {
+    const uintptr_t page = 4096;
+    const uintptr_t lo = (uintptr_t)host & ~(page - 1), hi = ((uintptr_t)host + bytes + page - 1) & ~(page - 1);
+    std::vector<std::pair<uintptr_t, uintptr_t>> todo{{lo, hi}};
+    for (const auto& pin : c->pins) {
+        const uintptr_t a = (uintptr_t)pin.p, b = a + pin.bytes;
+        std::vector<std::pair<uintptr_t, uintptr_t>> rest;
+        for (const auto& seg : todo) {
+            if (b <= seg.first || a >= seg.second) { rest.push_back(seg); continue; }
+            if (seg.first < a) rest.emplace_back(seg.first, a);
+            if (b < seg.second) rest.emplace_back(b, seg.second);
+        }
+        todo.swap(rest);
+    }
+    for (const auto& seg : todo) {
+        const hipError_t e = hipHostRegister((void*)seg.first, seg.second - seg.first, hipHostRegisterDefault);
+        if (e != hipSuccess) return hip_fail(e, "hipHostRegister");
+        c->pins.push_back({(char*)seg.first, (size_t)(seg.second - seg.first), false});
+    }
+    return DRAY_OK;
+}
+
+// The whole frame into host buffers: see dray_context_render in dray.h.
+int context_render_locked(dray_context* c, const dray_camera* cam, uint32_t* color, double* raw, int32_t* count,
+                          size_t buf_len, const dray_opts* opts_in, uint32_t sync, dray_stats* stats) {
     const auto t_begin = std::chrono::steady_clock::now();
-    if (!camera_ok(cam) || !color || (!spheres && n)) return DRAY_ERR_INVALID_ARG;
+    if (!camera_ok(cam) || !color) return DRAY_ERR_INVALID_ARG;
+    if (!c->have_scene) {
+        snprintf(g_detail, sizeof g_detail, "the context has no scene: call dray_context_set_scene first");
+        return DRAY_ERR_INVALID_ARG;
+    }
     dray_opts opts;
     if (opts_in) opts = *opts_in; else dray_opts_default(&opts);
     // the row partition is this call's to make
     if (opts.row_begin != 0 || opts.row_step > 1 || (opts.flags & DRAY_FLAG_COMPACT_ROWS)) return DRAY_ERR_INVALID_ARG;
-    int visible = 0;
-    if (hipGetDeviceCount(&visible) != hipSuccess || visible < 1) return DRAY_ERR_NO_DEVICE;
-    std::vector<int32_t> devs;
-    if (n_devices <= 0) n_devices = visible;              // every visible GPU
-    if (n_devices > 64) return DRAY_ERR_INVALID_ARG;
-    for (int32_t k = 0; k < n_devices; ++k) {
-        const int32_t d = devices ? devices[k] : k;
-        if (d < 0 || d >= visible) return DRAY_ERR_INVALID_ARG;
-        devs.push_back(d);
-    }
-    for (size_t k = 0; k < n; ++k)
-        if (!entry_ok(spheres[k])) return DRAY_ERR_UNSUPPORTED;
+    if (opts.mode > DRAY_MODE_F32_PLAIN || opts.variant < 0 || opts.variant > DRAY_SCAN_GRID) return DRAY_ERR_INVALID_ARG;
+    if (sync & ~(uint32_t)(DRAY_SYNC_UPLOAD_SUMS | DRAY_SYNC_DOWNLOAD_SUMS)) return DRAY_ERR_INVALID_ARG;
     dray_camera_derived dv;
     int rc = dray_camera_initialize(cam, &dv);
     if (rc) return rc;
     const size_t W = (size_t)cam->image_width, H = (size_t)dv.image_height;
     if (buf_len < W * H) return DRAY_ERR_BUFFER_TOO_SMALL;
     const bool exact_product = opts.mode != DRAY_MODE_F32 && !(opts.flags & DRAY_FLAG_ITERATIVE_PRODUCT);
-    if (opts.mode > DRAY_MODE_F32_PLAIN || opts.variant < 0 || opts.variant > DRAY_SCAN_GRID) return DRAY_ERR_INVALID_ARG;
     if (exact_product && cam->max_depth > kExactMaxDepth) return DRAY_ERR_UNSUPPORTED;
+    const int32_t G = (int32_t)c->shares.size();
     if (stats) {
         std::memset(stats, 0, sizeof *stats);
         stats->image_height = (int32_t)H;
-        stats->n_spheres = (int32_t)n;
+        stats->n_spheres = (int32_t)c->spheres.size();
     }
     if (cam->samples_per_pixel <= 0) return DRAY_OK; // camera.rs:217: no samples, no writes
-
-    const int32_t G = (int32_t)devs.size();
-    std::vector<dray_stats> st((size_t)G);
-    std::vector<int> rcs((size_t)G, DRAY_OK);
-    std::vector<std::string> detail((size_t)G);
-    std::vector<std::thread> workers;
-    workers.reserve((size_t)G);
-    bool started_all = true;
-    for (int32_t g = 0; g < G && started_all; ++g) try {
-        workers.emplace_back([&, g]() {
-            try { // nothing may leave a thread by unwinding
-                rcs[g] = render_share(cam, spheres, n, color, raw, count, opts, devs[g], g, G, W, H, &st[g]);
-                if (rcs[g]) detail[g] = g_detail; // the failure text lives in the worker's thread
-            } catch (...) {
-                rcs[g] = DRAY_ERR_INTERNAL;
-            }
-        });
-    } catch (...) { // no thread to be had: wait for those that did start, then give up
-        started_all = false;
-    }
-    for (auto& w : workers) w.join();
-    if (!started_all) return DRAY_ERR_INTERNAL;
-    for (int32_t g = 0; g < G; ++g)
-        if (rcs[g]) {
-            snprintf(g_detail, sizeof g_detail, "device %d: %s", devs[g], detail[g].c_str());
-            return rcs[g];
+    const bool upload = (sync & DRAY_SYNC_UPLOAD_SUMS) != 0, download = (sync & DRAY_SYNC_DOWNLOAD_SUMS) != 0;
+    if (!upload && (raw || count)) {
+        // the sums stay where the previous call left them, on the device: it must have been this frame's call
+        if (c->res_W != (int32_t)W || c->res_H != (int32_t)H || c->res_raw != (raw != nullptr) || c->res_count != (count != nullptr)) {
+            snprintf(g_detail, sizeof g_detail, "no running sums of a %zu x %zu frame are resident: pass DRAY_SYNC_UPLOAD_SUMS", W, H);
+            return DRAY_ERR_INVALID_ARG;
         }
+    }
+    c->res_W = c->res_H = 0; // until this call has gone through
+
+    const bool direct_color = G > 0 && pinned(c, color, W * H * sizeof(uint32_t));
+    const bool direct_raw = raw && pinned(c, raw, W * H * 3 * sizeof(double));
+    const bool direct_count = count && pinned(c, count, W * H * sizeof(int32_t));
+
+    struct Fail { // on any failure: let go of the scenes, drain what was enqueued
+        dray_context* c;
+        bool armed = true;
+        ~Fail() {
+            if (!armed) return;
+            for (CtxShare& sh : c->shares) {
+                if (!sh.active) continue;
+                sh.job.abandon();
+                DeviceGuard g(sh.device);
+                (void)hipStreamSynchronize(sh.copy);
+                (void)hipStreamSynchronize(sh.compute);
+                sh.active = false;
+            }
+        }
+    } guard{c};
+#define CTX_TRY(expr)                                      \
+    do {                                                   \
+        hipError_t e__ = (expr);                           \
+        if (e__ != hipSuccess) return hip_fail(e__, #expr); \
+    } while (0)
+
+    // ---- set-up per share: slabs and staging large enough, the job checked ----------------------------------
+    for (int32_t k = 0; k < G; ++k) {
+        CtxShare& sh = c->shares[(size_t)k];
+        sh.active = false;
+        std::memset(&sh.stats, 0, sizeof sh.stats);
+        const size_t n_rows = (size_t)k < H ? (H - (size_t)k + (size_t)G - 1) / (size_t)G : 0;
+        if (n_rows == 0) continue;
+        const size_t slab = n_rows * W;
+        DeviceGuard g(sh.device);
+        if (g.err != hipSuccess) return hip_fail(g.err, "hipSetDevice");
+        if (slab > sh.cap) {
+            CTX_TRY(hipStreamSynchronize(sh.compute));
+            (void)hipFree(sh.d_color); (void)hipFree(sh.d_raw); (void)hipFree(sh.d_count);
+            sh.d_color = nullptr; sh.d_raw = nullptr; sh.d_count = nullptr; sh.cap = 0;
+            CTX_TRY(hipMalloc((void**)&sh.d_color, slab * sizeof(uint32_t)));
+            CTX_TRY(hipMalloc((void**)&sh.d_raw, slab * 3 * sizeof(double)));
+            CTX_TRY(hipMalloc((void**)&sh.d_count, slab * sizeof(int32_t)));
+            sh.cap = slab;
+        }
+        const size_t stage_need = slab * (sizeof(uint32_t) + 3 * sizeof(double) + sizeof(int32_t));
+        if (!(direct_color && (!raw || direct_raw) && (!count || direct_count)) && stage_need > sh.stage_bytes) {
+            CTX_TRY(hipStreamSynchronize(sh.compute));
+            if (sh.stage) (void)hipHostFree(sh.stage);
+            sh.stage = nullptr; sh.stage_bytes = 0;
+            CTX_TRY(hipHostMalloc((void**)&sh.stage, stage_need, hipHostMallocDefault));
+            sh.stage_bytes = stage_need;
+        }
+        dray_opts o = opts;
+        o.device = sh.device;
+        o.row_begin = k;
+        o.row_step = G;
+        o.flags |= DRAY_FLAG_COMPACT_ROWS;
+        rc = sh.job.prepare(cam, sh.scene, true, slab, &o, sh.compute, false, &sh.stats);
+        if (rc) return rc;
+        sh.active = !sh.job.empty;
+    }
+    // ---- every share's trace kernel starts before any host-side copying ----------------------------------------
+    for (CtxShare& sh : c->shares)
+        if (sh.active && (rc = sh.job.begin())) return rc;
+
+    // image row k + r G of the caller's buffer <-> slab row r; `elem` bytes per pixel
+    auto rows = [&](CtxShare& sh, int32_t k, void* dev, void* host, size_t elem, bool to_device, bool direct, char* stage,
+                    hipStream_t stream) -> hipError_t {
+        const size_t n_rows = (H - (size_t)k + (size_t)G - 1) / (size_t)G;
+        char* h = (char*)host + (size_t)k * W * elem;
+        const size_t row = W * elem, host_pitch = (size_t)G * row;
+        const hipMemcpyKind kind = to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost;
+        if (direct) { // registered memory: the copy engine reads or writes the caller's rows itself
+            if (G == 1) return to_device ? hipMemcpyAsync(dev, h, n_rows * row, kind, stream) : hipMemcpyAsync(h, dev, n_rows * row, kind, stream);
+            return to_device ? hipMemcpy2DAsync(dev, row, h, host_pitch, row, n_rows, kind, stream)
+                             : hipMemcpy2DAsync(h, host_pitch, dev, row, row, n_rows, kind, stream);
+        }
+        if (to_device) { // gather the rows into the pinned block, one copy from there
+            for (size_t r = 0; r < n_rows; ++r) std::memcpy(stage + r * row, h + r * host_pitch, row);
+            return hipMemcpyAsync(dev, stage, n_rows * row, kind, stream);
+        }
+        return hipMemcpyAsync(stage, dev, n_rows * row, kind, stream); // scattered to the rows after the stream is done
+    };
+    // ---- the sums the render adds to go up while the trace kernels run; then the kernels that need them ---------
+    for (int32_t k = 0; k < G; ++k) {
+        CtxShare& sh = c->shares[(size_t)k];
+        if (!sh.active) continue;
+        DeviceGuard g(sh.device);
+        const size_t slab = (size_t)sh.job.part.n_rows * W;
+        char* st_raw = sh.stage ? sh.stage + slab * sizeof(uint32_t) : nullptr;
+        char* st_count = sh.stage ? st_raw + slab * 3 * sizeof(double) : nullptr;
+        bool sent = false;
+        if (upload && raw) { CTX_TRY(rows(sh, k, sh.d_raw, raw, 3 * sizeof(double), true, direct_raw, st_raw, sh.copy)); sent = true; }
+        if (upload && count) { CTX_TRY(rows(sh, k, sh.d_count, count, sizeof(int32_t), true, direct_count, st_count, sh.copy)); sent = true; }
+        if (sent) CTX_TRY(hipEventRecord(sh.uploaded, sh.copy));
+        if ((rc = sh.job.finish(sh.d_color, raw ? sh.d_raw : nullptr, count ? sh.d_count : nullptr, sent ? sh.uploaded : nullptr)))
+            return rc;
+        // results come back on the compute stream, behind the kernels
+        CTX_TRY(rows(sh, k, sh.d_color, color, sizeof(uint32_t), false, direct_color, sh.stage, sh.compute));
+        if (download && raw) CTX_TRY(rows(sh, k, sh.d_raw, raw, 3 * sizeof(double), false, direct_raw, st_raw, sh.compute));
+        if (download && count) CTX_TRY(rows(sh, k, sh.d_count, count, sizeof(int32_t), false, direct_count, st_count, sh.compute));
+    }
+    // ---- wait, hand the staged rows out, collect the statistics ---------------------------------------------------
+    for (int32_t k = 0; k < G; ++k) {
+        CtxShare& sh = c->shares[(size_t)k];
+        if (!sh.active) continue;
+        DeviceGuard g(sh.device);
+        CTX_TRY(hipStreamSynchronize(sh.compute));
+        const size_t n_rows = (size_t)sh.job.part.n_rows, slab = n_rows * W;
+        auto scatter = [&](void* host, const char* stage, size_t elem) {
+            char* h = (char*)host + (size_t)k * W * elem;
+            const size_t row = W * elem, host_pitch = (size_t)G * row;
+            for (size_t r = 0; r < n_rows; ++r) std::memcpy(h + r * host_pitch, stage + r * row, row);
+        };
+        if (!direct_color) scatter(color, sh.stage, sizeof(uint32_t));
+        if (download && raw && !direct_raw) scatter(raw, sh.stage + slab * sizeof(uint32_t), 3 * sizeof(double));
+        if (download && count && !direct_count) scatter(count, sh.stage + slab * (sizeof(uint32_t) + 3 * sizeof(double)), sizeof(int32_t));
+        if ((rc = sh.job.collect(&sh.stats))) return rc;
+        sh.active = false;
+    }
+#undef CTX_TRY
+    guard.armed = false;
+    c->res_W = (int32_t)W; c->res_H = (int32_t)H; c->res_raw = raw != nullptr; c->res_count = count != nullptr;
     if (stats) {
-        for (const dray_stats& s : st) {
+        for (const CtxShare& sh : c->shares) {
+            const dray_stats& s = sh.stats;
             stats->segments += s.segments; stats->samples += s.samples; stats->walk_steps += s.walk_steps;
             stats->rows_rendered += s.rows_rendered;
             stats->kernel_ms = std::fmax(stats->kernel_ms, s.kernel_ms);   // the shares run side by side
@@ -899,14 +1153,80 @@ int render_multi_impl(const dray_camera* cam, const dray_sphere* spheres, size_t
     return DRAY_OK;
 }
 
-int resolve_device(const dray_opts& opts, int* device) {
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return DRAY_ERR_NO_DEVICE;
-    *device = opts.device;
-    if (*device < 0) HIP_TRY(hipGetDevice(device));
-    if (*device >= ndev) return DRAY_ERR_INVALID_ARG;
-    return DRAY_OK;
+// The contexts behind dray_render and dray_render_multi: one per list of devices, kept until dray_release_cache or
+// the end of the process, so that a second call with the same sphere list finds scene, grid and buffers in place.
+std::mutex g_cache_mu;
+std::vector<std::pair<std::vector<int32_t>, dray_context*>> g_cache;
+
+int cached_render(const std::vector<int32_t>& devs, const dray_camera* cam, const dray_sphere* spheres, size_t n,
+                  uint32_t* color, double* raw, int32_t* count, size_t buf_len, const dray_opts* opts, dray_stats* stats) {
+    const auto t_begin = std::chrono::steady_clock::now();
+    dray_context* c = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_cache_mu);
+        for (auto& e : g_cache)
+            if (e.first == devs) c = e.second;
+        if (!c) {
+            if (g_cache.size() >= 8) { // a handful of device lists at most: drop the oldest
+                std::lock_guard<std::mutex> busy(g_cache.front().second->mu);
+                context_free(g_cache.front().second);
+                g_cache.erase(g_cache.begin());
+            }
+            const int rc = context_create_impl(devs.data(), (int32_t)devs.size(), &c);
+            if (rc) return rc;
+            g_cache.emplace_back(devs, c);
+        }
+    }
+    std::lock_guard<std::mutex> lock(c->mu);
+    // argument errors come before any device work, as they always did
+    if (!camera_ok(cam) || !color || (!spheres && n)) return DRAY_ERR_INVALID_ARG;
+    int rc = context_set_scene_locked(c, spheres, n);
+    if (rc) return rc;
+    rc = context_render_locked(c, cam, color, raw, count, buf_len, opts, DRAY_SYNC_UPLOAD_SUMS | DRAY_SYNC_DOWNLOAD_SUMS, stats);
+    if (rc == DRAY_OK && stats)
+        stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    return rc;
 }
+
+// Camera::render over several GPUs from one process.
+int render_multi_impl(const dray_camera* cam, const dray_sphere* spheres, size_t n, uint32_t* color, double* raw,
+                      int32_t* count, size_t buf_len, const dray_opts* opts_in, const int32_t* devices, int32_t n_devices,
+                      dray_stats* stats) {
+    if (!camera_ok(cam) || !color || (!spheres && n)) return DRAY_ERR_INVALID_ARG;
+    if (opts_in) { // the row partition is this call's to make
+        if (opts_in->row_begin != 0 || opts_in->row_step > 1 || (opts_in->flags & DRAY_FLAG_COMPACT_ROWS)) return DRAY_ERR_INVALID_ARG;
+        if (opts_in->mode > DRAY_MODE_F32_PLAIN || opts_in->variant < 0 || opts_in->variant > DRAY_SCAN_GRID) return DRAY_ERR_INVALID_ARG;
+    }
+    for (size_t k = 0; k < n; ++k)
+        if (!entry_ok(spheres[k])) return DRAY_ERR_UNSUPPORTED;
+    int visible = 0;
+    if (hipGetDeviceCount(&visible) != hipSuccess || visible < 1) return DRAY_ERR_NO_DEVICE;
+    std::vector<int32_t> devs;
+    if (n_devices <= 0) n_devices = visible;              // every visible GPU
+    if (n_devices > 64) return DRAY_ERR_INVALID_ARG;
+    for (int32_t k = 0; k < n_devices; ++k) {
+        const int32_t d = devices ? devices[k] : k;
+        if (d < 0 || d >= visible) return DRAY_ERR_INVALID_ARG;
+        devs.push_back(d);
+    }
+    return cached_render(devs, cam, spheres, n, color, raw, count, buf_len, opts_in, stats);
+}
+
+// Camera::render on one GPU.  A call that names a row partition of its own takes the plain route (render_host_impl).
+int render_one_impl(const dray_camera* cam, const dray_sphere* spheres, size_t n, uint32_t* color, double* raw,
+                    int32_t* count, size_t buf_len, const dray_opts* opts_in, dray_stats* stats) {
+    dray_opts opts;
+    if (opts_in) opts = *opts_in; else dray_opts_default(&opts);
+    if (opts.row_begin != 0 || (opts.row_step != 0 && opts.row_step != 1) || (opts.flags & DRAY_FLAG_COMPACT_ROWS))
+        return render_host_impl(cam, spheres, n, color, raw, count, buf_len, opts_in, stats);
+    if (!camera_ok(cam) || !color || (!spheres && n)) return DRAY_ERR_INVALID_ARG;
+    int device = -1;
+    const int rc = resolve_device(opts, &device);
+    if (rc) return rc;
+    opts.device = -1; // the context's share names the device
+    return cached_render(std::vector<int32_t>{device}, cam, spheres, n, color, raw, count, buf_len, &opts, stats);
+}
+
 
 int camera_rays_device_impl(const dray_camera* cam, const dray_pixel_index* d_px, size_t n, dray_path_entry* d_out,
                             const dray_opts* opts_in, void* stream_v) {
@@ -1097,7 +1417,7 @@ int dray_camera_initialize(const dray_camera* cam, dray_camera_derived* out) { /
 int dray_render(const dray_camera* cam, const dray_sphere* spheres, size_t n_spheres, uint32_t* color, double* raw,
                 int32_t* count, size_t buf_len, const dray_opts* opts, dray_stats* stats) {
     try {
-        return render_host_impl(cam, spheres, n_spheres, color, raw, count, buf_len, opts, stats);
+        return render_one_impl(cam, spheres, n_spheres, color, raw, count, buf_len, opts, stats);
     } catch (...) {
         return DRAY_ERR_INTERNAL;
     }
@@ -1110,6 +1430,100 @@ int dray_render_multi(const dray_camera* cam, const dray_sphere* spheres, size_t
         return render_multi_impl(cam, spheres, n_spheres, color, raw, count, buf_len, opts, devices, n_devices, stats);
     } catch (...) {
         return DRAY_ERR_INTERNAL;
+    }
+}
+
+void dray_release_cache(void) {
+    try {
+        std::lock_guard<std::mutex> lock(g_cache_mu);
+        for (auto& e : g_cache) {
+            { std::lock_guard<std::mutex> busy(e.second->mu); } // a call in flight on another thread finishes first
+            context_free(e.second);
+        }
+        g_cache.clear();
+    } catch (...) {
+    }
+}
+
+int dray_context_create(const int32_t* devices, int32_t n_devices, dray_context** out) {
+    try {
+        return context_create_impl(devices, n_devices, out);
+    } catch (...) {
+        return DRAY_ERR_INTERNAL;
+    }
+}
+
+void dray_context_destroy(dray_context* ctx) {
+    try {
+        if (ctx) { std::lock_guard<std::mutex> busy(ctx->mu); }
+        context_free(ctx);
+    } catch (...) {
+    }
+}
+
+int dray_context_set_scene(dray_context* ctx, const dray_sphere* spheres, size_t n_spheres) {
+    try {
+        if (!ctx) return DRAY_ERR_INVALID_ARG;
+        std::lock_guard<std::mutex> lock(ctx->mu);
+        return context_set_scene_locked(ctx, spheres, n_spheres);
+    } catch (...) {
+        return DRAY_ERR_INTERNAL;
+    }
+}
+
+int dray_context_render(dray_context* ctx, const dray_camera* cam, uint32_t* color, double* raw, int32_t* count,
+                        size_t buf_len, const dray_opts* opts, uint32_t sync, dray_stats* stats) {
+    try {
+        if (!ctx) return DRAY_ERR_INVALID_ARG;
+        std::lock_guard<std::mutex> lock(ctx->mu);
+        return context_render_locked(ctx, cam, color, raw, count, buf_len, opts, sync, stats);
+    } catch (...) {
+        return DRAY_ERR_INTERNAL;
+    }
+}
+
+int dray_context_pin(dray_context* ctx, void* host, size_t bytes) {
+    try {
+        if (!ctx || !host || bytes == 0) return DRAY_ERR_INVALID_ARG;
+        std::lock_guard<std::mutex> lock(ctx->mu);
+        return context_pin_locked(ctx, host, bytes);
+    } catch (...) {
+        return DRAY_ERR_INTERNAL;
+    }
+}
+
+int dray_context_host_alloc(dray_context* ctx, size_t bytes, void** out) {
+    try {
+        if (!ctx || !out || bytes == 0) return DRAY_ERR_INVALID_ARG;
+        *out = nullptr;
+        std::lock_guard<std::mutex> lock(ctx->mu);
+        void* p = nullptr;
+        const hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocPortable);
+        if (e != hipSuccess) return hip_fail(e, "hipHostMalloc");
+        std::memset(p, 0, bytes);
+        ctx->pins.push_back({(char*)p, bytes, true});
+        *out = p;
+        return DRAY_OK;
+    } catch (...) {
+        return DRAY_ERR_INTERNAL;
+    }
+}
+
+void dray_context_unpin(dray_context* ctx) {
+    try {
+        if (!ctx) return;
+        std::lock_guard<std::mutex> lock(ctx->mu);
+        for (CtxShare& sh : ctx->shares) {
+            DeviceGuard g(sh.device);
+            if (sh.compute) (void)hipStreamSynchronize(sh.compute);
+        }
+        std::vector<dray_context::Pin> keep;
+        for (auto& pin : ctx->pins) {
+            if (pin.owned) keep.push_back(pin); // the context's own allocations live until it is destroyed
+            else (void)hipHostUnregister(pin.p);
+        }
+        ctx->pins.swap(keep);
+    } catch (...) {
     }
 }
 

@@ -147,6 +147,83 @@ def flatten_world(world):
     return np.array(rows, dtype=_ffi.SPHERE_DTYPE) if rows else np.zeros(0, dtype=_ffi.SPHERE_DTYPE)
 
 
+# --------------------------------------------------------------------- context --
+
+class RenderContext:
+    """A dray_context: scenes, device buffers and staging memory kept between render calls (include/dray.h).
+
+    ``devices``: None = the current device, "all" = every visible GPU, or a list of device numbers (share k renders
+    scanlines k, k + G, ...).  Give it to a camera (``cam.context = ctx``) and ``Camera.render`` goes through it."""
+
+    def __init__(self, devices=None):
+        h = C.c_void_p()
+        if devices is None:
+            import torch
+            devs = np.array([torch.cuda.current_device() if torch.cuda.is_available() else 0], dtype=np.int32)
+        elif isinstance(devices, str):
+            devs = None
+        else:
+            devs = np.ascontiguousarray(devices, dtype=np.int32)
+        _ffi.check(_ffi.lib().dray_context_create(devs.ctypes.data if devs is not None else None,
+                                                  len(devs) if devs is not None else 0, C.byref(h)))
+        self._h = h
+        self._pinned = []
+
+    @property
+    def handle(self):
+        if self._h is None:
+            raise DrayError(_ffi.ERR_INVALID_ARG, "context already destroyed")
+        return self._h
+
+    def set_scene(self, world):
+        spheres = flatten_world(world)
+        _ffi.check(_ffi.lib().dray_context_set_scene(self.handle, spheres.ctypes.data if len(spheres) else None, len(spheres)))
+
+    def pin(self, *buffers):
+        """Register numpy buffers with the HIP runtime so that copies go straight to and from them; the context keeps
+        a reference to each until unpin() or close()."""
+        for b in buffers:
+            if b is None:
+                continue
+            _ffi.check(_ffi.lib().dray_context_pin(self.handle, b.ctypes.data, b.nbytes))
+            self._pinned.append(b)
+
+    def alloc_buffers(self, n_pixels):
+        """(color uint32[n], raw float64[n, 3], count int32[n]) in page-locked memory of the context: zeroed, reached by
+        the copy engines without staging, valid until close()."""
+        out = []
+        for dtype, shape in ((np.uint32, (n_pixels,)), (np.float64, (n_pixels, 3)), (np.int32, (n_pixels,))):
+            nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+            p = C.c_void_p()
+            _ffi.check(_ffi.lib().dray_context_host_alloc(self.handle, nbytes, C.byref(p)))
+            buf = (C.c_char * nbytes).from_address(p.value)
+            out.append(np.frombuffer(buf, dtype=dtype).reshape(shape))
+        return tuple(out)
+
+    def unpin(self):
+        if self._h is not None:
+            _ffi.lib().dray_context_unpin(self._h)
+        self._pinned = []
+
+    def render(self, pod, color_buffer, raw_buffer, count_buffer, buf_len, opts, sync, stats):
+        return _ffi.lib().dray_context_render(
+            self.handle, C.byref(pod), color_buffer.ctypes.data,
+            raw_buffer.ctypes.data if raw_buffer is not None else None,
+            count_buffer.ctypes.data if count_buffer is not None else None, buf_len, C.byref(opts), sync, C.byref(stats))
+
+    def close(self):
+        if self._h is not None:
+            _ffi.lib().dray_context_destroy(self._h)
+            self._h = None
+            self._pinned = []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 # ---------------------------------------------------------------------- camera --
 
 class Camera:
@@ -175,6 +252,9 @@ class Camera:
         # GPUs of this node to spread a render over from this one process: None = the one device above; a list of
         # device numbers (a device may appear more than once); "all" = every visible GPU
         self.devices = None
+        # a RenderContext to render through (its devices then count, not `devices`): the world is uploaded and its grid
+        # built when it changes, not per call, and the passes of a progressive render leave the sums on the device
+        self.context = None
         self.last_stats = None
 
     @classmethod
@@ -241,6 +321,11 @@ class Camera:
         first_sample = opts.sample_offset
         done = 0
         whole = None
+        ctx = self.context
+        if ctx is not None:
+            if opts_row_partition(opts):
+                raise DrayError(_ffi.ERR_INVALID_ARG, "a context makes the row partition itself")
+            ctx.set_scene(spheres)   # a no-op when the list is the one the context holds
         while True:  # at least one call, so that a camera of 0 samples fails (or not) the way one call does
             pod.samples_per_pixel = min(per_pass, total - done) if total > 0 else total
             opts.sample_offset = first_sample + done
@@ -248,7 +333,12 @@ class Camera:
             args = (C.byref(pod), spheres.ctypes.data if len(spheres) else None, len(spheres), color_buffer.ctypes.data,
                     raw_buffer.ctypes.data if raw_buffer is not None else None,
                     count_buffer.ctypes.data if count_buffer is not None else None, buf_len, C.byref(opts))
-            if self.devices is None:
+            if ctx is not None:
+                # the sums go up with the first pass and come back with the last; in between only the colours move
+                last = total <= 0 or done + pod.samples_per_pixel >= total
+                sync = (_ffi.SYNC_UPLOAD_SUMS if done == 0 else 0) | (_ffi.SYNC_DOWNLOAD_SUMS if last else 0)
+                rc = ctx.render(pod, color_buffer, raw_buffer, count_buffer, buf_len, opts, sync, st)
+            elif self.devices is None:
                 rc = _ffi.lib().dray_render(*args, C.byref(st))
             elif isinstance(self.devices, str):  # "all"
                 rc = _ffi.lib().dray_render_multi(*args, None, 0, C.byref(st))
@@ -271,6 +361,10 @@ class Camera:
                 break
         self.last_stats = whole
         return None  # Ok(())
+
+
+def opts_row_partition(opts):
+    return opts.row_begin != 0 or opts.row_step not in (0, 1) or (opts.flags & FLAG_COMPACT_ROWS) != 0
 
 
 def write_ppm(path, color_buffer, width=None, height=None, binary=False):

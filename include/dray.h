@@ -200,6 +200,44 @@ int dray_render_multi(const dray_camera* cam, const dray_sphere* spheres, size_t
                       int32_t* count, size_t buf_len, const dray_opts* opts, const int32_t* devices, int32_t n_devices,
                       dray_stats* stats);
 
+/* dray_render and dray_render_multi keep what a second call can use again -- the scene tables and the grid built from
+ * the sphere list (reused when the next call's list is byte for byte the same), device buffers, pinned staging
+ * memory, streams -- in a cache per list of devices.  This frees all of it (no call may be in flight). */
+void dray_release_cache(void);
+
+/* ---- a render context: the one-call route with its set-up kept between calls ------------------------------- */
+/* What dray_render_multi does per call, split so that a caller who renders the same world again and again -- the
+ * passes of a progressive display, the frames of a camera move -- pays for it once: dray_context_create takes the
+ * devices (entry k renders scanlines k, k + n_devices, ...; NULL / 0 = every visible GPU), dray_context_set_scene
+ * builds the sphere tables and the grid on each of them, dray_context_render is Camera::render (camera.rs:208-236)
+ * into the caller's host buffers with the contract of dray_render (opts->device, row_begin, row_step and
+ * DRAY_FLAG_COMPACT_ROWS left at their defaults).  No counterpart in the reference, whose render call is made once.
+ *
+ * `sync` says what happens to the running sums (raw, count), which live in device memory between calls:
+ *   DRAY_SYNC_UPLOAD_SUMS    the device copy is first loaded from the caller's raw / count (what dray_render does);
+ *                            without it the render adds to what the context's previous call left on the device, which
+ *                            must have been a call for the same frame size (else DRAY_ERR_INVALID_ARG)
+ *   DRAY_SYNC_DOWNLOAD_SUMS  raw / count are written back to the caller's buffers; without it only `color` is
+ * so a progressive render is: first pass UPLOAD, passes in between 0, last pass DOWNLOAD, and each pass moves only
+ * the 4 bytes per pixel of the colour buffer.  dray_render = UPLOAD | DOWNLOAD in one call.
+ *
+ * Buffers in page-locked host memory are read and written by the copy engines directly, rows and all; others are
+ * staged through the context's own pinned block by the CPU (two copies of every byte more).  dray_context_host_alloc
+ * hands out zeroed page-locked memory that lives until dray_context_destroy; dray_context_pin registers memory the
+ * caller already has (hipHostRegister; it must stay allocated until dray_context_unpin or dray_context_destroy, and
+ * the call returns DRAY_ERR_HIP where the driver refuses such registrations -- the render then stages as usual).
+ * A context serves one call at a time (calls from several threads take turns). */
+typedef struct dray_context dray_context;
+enum { DRAY_SYNC_UPLOAD_SUMS = 1u, DRAY_SYNC_DOWNLOAD_SUMS = 2u };
+int dray_context_create(const int32_t* devices, int32_t n_devices, dray_context** out);
+void dray_context_destroy(dray_context* ctx);
+int dray_context_set_scene(dray_context* ctx, const dray_sphere* spheres, size_t n_spheres);
+int dray_context_render(dray_context* ctx, const dray_camera* cam, uint32_t* color, double* raw, int32_t* count,
+                        size_t buf_len, const dray_opts* opts, uint32_t sync, dray_stats* stats);
+int dray_context_host_alloc(dray_context* ctx, size_t bytes, void** out);
+int dray_context_pin(dray_context* ctx, void* host, size_t bytes);
+void dray_context_unpin(dray_context* ctx);
+
 /* ---- device-resident variant (buffers already in HBM) --------------------- */
 /* Upload the sphere list of a HittableList (hittable_list.rs:7-9) to `device`. */
 int dray_scene_create(const dray_sphere* spheres, size_t n_spheres, int32_t device, dray_scene** out);

@@ -169,6 +169,39 @@ class HittableList : public Hittable {
     std::vector<std::shared_ptr<Hittable>> objects;
 };
 
+// ---- render context ----------------------------------------------------------------------------------------
+// A dray_context: the scenes, device buffers and staging memory of the one-call route, kept between calls.  Share k of
+// `devices` renders scanlines k, k + G, ...; an empty list means every visible GPU.
+class RenderContext {
+  public:
+    explicit RenderContext(const std::vector<int32_t>& devices = {}) {
+        const int rc = dray_context_create(devices.empty() ? nullptr : devices.data(), (int32_t)devices.size(), &ctx_);
+        if (rc != DRAY_OK) throw Error(rc, std::string("RenderContext: ") + dray_strerror(rc));
+    }
+    ~RenderContext() { dray_context_destroy(ctx_); }
+    RenderContext(const RenderContext&) = delete;
+    RenderContext& operator=(const RenderContext&) = delete;
+    dray_context* handle() const { return ctx_; }
+    // registers the buffer with the HIP runtime: copies then go straight to and from it.  It must outlive unpin().
+    // Returns false where the driver refuses such registrations (the render then stages through the context's block).
+    template <typename T>
+    bool pin(std::vector<T>& buffer) {
+        return dray_context_pin(ctx_, buffer.data(), buffer.size() * sizeof(T)) == DRAY_OK;
+    }
+    // zeroed page-locked memory of the context for `n` elements, valid until the context goes
+    template <typename T>
+    T* host_alloc(size_t n) {
+        void* p = nullptr;
+        const int rc = dray_context_host_alloc(ctx_, n * sizeof(T), &p);
+        if (rc != DRAY_OK) throw Error(rc, std::string("RenderContext::host_alloc: ") + dray_strerror(rc));
+        return static_cast<T*>(p);
+    }
+    void unpin() { dray_context_unpin(ctx_); }
+
+  private:
+    dray_context* ctx_ = nullptr;
+};
+
 // ---- camera ------------------------------------------------------------------------------------------------
 class Camera {
   public:
@@ -191,6 +224,9 @@ class Camera {
     // GPUs of this node to spread a render over from this one process (dray_render_multi); empty: the one device of
     // `opts`.  A device may appear more than once.
     std::vector<int32_t> devices;
+    // a context to render through (its devices then count, not `devices`): the world is uploaded and its grid built
+    // when it changes, not per call, and the passes of a progressive render leave the running sums on the device
+    RenderContext* context = nullptr;
     dray_stats last_stats{}; // of the whole call (counts and times summed over its passes)
 
     Camera() { dray_opts_default(&opts); }
@@ -238,17 +274,26 @@ class Camera {
         dray_opts o = opts;
         dray_stats whole{};
         int32_t done = 0;
+        const dray_sphere* sp = spheres.empty() ? nullptr : spheres.data();
+        if (context) check(dray_context_set_scene(context->handle(), sp, spheres.size()), "Camera::render"); // a no-op for the list it holds
         do { // at least one call, so that a camera of 0 samples fails (or not) the way one call does
             c.samples_per_pixel = total > 0 && total - done < per_pass ? total - done : per_pass;
             o.sample_offset = opts.sample_offset + (uint32_t)done;
             dray_stats st{};
-            const dray_sphere* sp = spheres.empty() ? nullptr : spheres.data();
             double* rawp = raw_buffer.empty() ? nullptr : raw_buffer.data();
             int32_t* cntp = count_buffer.empty() ? nullptr : count_buffer.data();
-            check(devices.empty() ? dray_render(&c, sp, spheres.size(), color_buffer.data(), rawp, cntp, buf_len, &o, &st)
-                                  : dray_render_multi(&c, sp, spheres.size(), color_buffer.data(), rawp, cntp, buf_len, &o,
-                                                      devices.data(), (int32_t)devices.size(), &st),
-                  "Camera::render");
+            if (context) {
+                // the sums go up with the first pass and come back with the last; in between only the colours move
+                const bool last = total <= 0 || done + c.samples_per_pixel >= total;
+                const uint32_t sync = (done == 0 ? (uint32_t)DRAY_SYNC_UPLOAD_SUMS : 0u) | (last ? (uint32_t)DRAY_SYNC_DOWNLOAD_SUMS : 0u);
+                check(dray_context_render(context->handle(), &c, color_buffer.data(), rawp, cntp, buf_len, &o, sync, &st),
+                      "Camera::render");
+            } else {
+                check(devices.empty() ? dray_render(&c, sp, spheres.size(), color_buffer.data(), rawp, cntp, buf_len, &o, &st)
+                                      : dray_render_multi(&c, sp, spheres.size(), color_buffer.data(), rawp, cntp, buf_len, &o,
+                                                          devices.data(), (int32_t)devices.size(), &st),
+                      "Camera::render");
+            }
             if (done == 0) {
                 whole = st;
             } else {

@@ -43,6 +43,9 @@ pub const DRAY_SCAN_GRID: i32 = 3;
 
 pub const DRAY_NOALLOC_MAX_PIXELS: usize = 1048576;
 
+pub const DRAY_SYNC_UPLOAD_SUMS: u32 = 1;
+pub const DRAY_SYNC_DOWNLOAD_SUMS: u32 = 2;
+
 // ---- structs ----------------------------------------------------------------------------------------------
 /// The ten public camera fields, camera.rs:42-53, same order.
 #[repr(C)]
@@ -138,6 +141,12 @@ pub struct dray_scene {
     _private: [u8; 0],
 }
 
+/// A render context (scenes, device buffers, staging kept between calls); only ever handled through a pointer.
+#[repr(C)]
+pub struct dray_context {
+    _private: [u8; 0],
+}
+
 /// PixelIndexEntry, camera.rs:8-13.
 #[repr(C)]
 #[derive(Clone, Copy, Debug, Default)]
@@ -211,6 +220,25 @@ extern "C" {
         n_devices: i32,
         stats: *mut dray_stats,
     ) -> c_int;
+
+    pub fn dray_release_cache();
+    pub fn dray_context_create(devices: *const i32, n_devices: i32, out: *mut *mut dray_context) -> c_int;
+    pub fn dray_context_destroy(ctx: *mut dray_context);
+    pub fn dray_context_set_scene(ctx: *mut dray_context, spheres: *const dray_sphere, n_spheres: usize) -> c_int;
+    pub fn dray_context_render(
+        ctx: *mut dray_context,
+        cam: *const dray_camera,
+        color: *mut u32,
+        raw: *mut f64,
+        count: *mut i32,
+        buf_len: usize,
+        opts: *const dray_opts,
+        sync: u32,
+        stats: *mut dray_stats,
+    ) -> c_int;
+    pub fn dray_context_host_alloc(ctx: *mut dray_context, bytes: usize, out: *mut *mut c_void) -> c_int;
+    pub fn dray_context_pin(ctx: *mut dray_context, host: *mut c_void, bytes: usize) -> c_int;
+    pub fn dray_context_unpin(ctx: *mut dray_context);
 
     pub fn dray_scene_create(spheres: *const dray_sphere, n_spheres: usize, device: i32, out: *mut *mut dray_scene) -> c_int;
     pub fn dray_scene_destroy(scene: *mut dray_scene);

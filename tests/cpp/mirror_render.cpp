@@ -76,6 +76,25 @@ int main(int argc, char** argv) {
             if (color4 != color || raw4 != raw || count4 != count) return 80;
             if (cam.last_stats.segments != first.segments || cam.last_stats.rows_rendered != H) return 81;
         }
+        // the same frame again through a render context on two shares, in passes of 3 samples with the caller's buffers
+        // registered: scene and grid built once, sums resident on the GPU between passes, only colours moving
+        {
+            std::vector<uint32_t> color5((size_t)W * W, 0u);
+            std::vector<double> raw5((size_t)W * W * 3, 0.0);
+            std::vector<int32_t> count5((size_t)W * W, 0);
+            RenderContext ctx({0, 0});
+            (void)ctx.pin(color5); (void)ctx.pin(raw5); (void)ctx.pin(count5); // refused by some drivers: then staged
+            cam.context = &ctx;
+            cam.samples_per_pass = 3;
+            presents = 0;
+            cam.render(world, [&](const std::vector<uint32_t>&, int32_t, int32_t) { ++presents; }, color5, raw5, count5);
+            cam.samples_per_pass = 0;
+            cam.context = nullptr;
+            ctx.unpin();
+            if (presents != (cam.samples_per_pixel + 2) / 3 && cam.samples_per_pixel > 3) return 82;
+            if (color5 != color || raw5 != raw || count5 != count) return 83;
+            if (cam.last_stats.segments != first.segments || cam.last_stats.samples != first.samples) return 84;
+        }
         // the same frame again through the resumable path state: rays for every (pixel, sample), stepped until all
         // are finished, colours summed per pixel in sample order (left-to-right product, camera.rs:118-144)
         unsigned long long step_segments = 0;

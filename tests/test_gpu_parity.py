@@ -759,6 +759,113 @@ def test_transparent_material(dray, gpu, oracle):
     assert dray.flatten_world(w)["kind"][0] == dray._ffi.MAT_TRANSPARENT
 
 
+def test_render_context(dray, gpu):
+    """dray_context_*: the one-call route with scene, grid, device buffers and staging kept between calls.  Whatever the
+    share count, with the caller's buffers registered or staged, in one call or in passes that leave the running sums
+    on the device, the three buffers end up as dray_render leaves them, bit for bit."""
+    world = dray.scene_final(1)
+    W = 80
+
+    def fresh():
+        return (np.full(W * W, 0xDEADBEEF, np.uint32), np.zeros((W * W, 3), np.float64), np.zeros(W * W, np.int32))
+
+    for mode in (dray.MODE_F64, dray.MODE_F32):
+        cam = dray.camera_final(width=W, spp=7, depth=8)   # 80 x 45
+        cam.mode, cam.seed = mode, 12
+        want = fresh()
+        cam.render(world, None, *want)          # dray_render
+        want_stats = cam.last_stats
+        H = cam.image_height
+        for devices in (None, [0], [0, 0, 0], "all"):
+            for pin in (False, True):
+                for per_pass in (0, 3):
+                    ctx = dray.RenderContext(devices)
+                    got = fresh()
+                    if pin:   # buffers in the context's page-locked memory: no staging
+                        got = ctx.alloc_buffers(W * W)
+                        got[0][:] = 0xDEADBEEF
+                    cam.context, cam.samples_per_pass = ctx, per_pass
+                    cam.render(world, None, *got)
+                    cam.render(world, None, *got, sample_offset=7)      # a second call adds to the first (colors.rs:38-39)
+                    cam.context, cam.samples_per_pass = None, 0
+                    got = tuple(b.copy() for b in got)
+                    ctx.close()
+                    ref = tuple(b.copy() for b in want)
+                    cam.render(world, None, *ref, sample_offset=7)
+                    for a, b in zip(got, ref):
+                        assert (a == b).all(), (mode, devices, pin, per_pass)
+                    assert (got[0][W * H:] == 0xDEADBEEF).all() and (got[2][W * H:] == 0).all()
+                    assert cam.last_stats.rows_rendered == H
+        assert want_stats.samples == 7 * W * H
+    # the pieces by hand
+    from dray_amd import _ffi
+    import ctypes as C
+    cam = dray.camera_final(width=W, spp=4, depth=8)
+    cam.mode, cam.seed = dray.MODE_F32, 3
+    ctx = dray.RenderContext([0, 0])
+    color, raw, count = fresh()
+    pod, opts, st = cam.pod(), cam.opts(), _ffi.Stats()
+    assert ctx.render(pod, color, raw, count, color.size, opts, 3, st) == _ffi.ERR_INVALID_ARG      # no scene yet
+    ctx.set_scene(world)
+    assert ctx.render(pod, color, raw, count, color.size, opts, 0, st) == _ffi.ERR_INVALID_ARG      # no sums resident yet
+    assert ctx.render(pod, color, raw, count, color.size, opts, 4, st) == _ffi.ERR_INVALID_ARG      # unknown sync bit
+    assert ctx.render(pod, color, raw, count, 100, opts, 3, st) == _ffi.ERR_BUFFER_TOO_SMALL
+    strided = cam.opts(row_begin=1, row_step=2)
+    assert ctx.render(pod, color, raw, count, color.size, strided, 3, st) == _ffi.ERR_INVALID_ARG   # the partition is the context's
+    assert (color == 0xDEADBEEF).all() and not raw.any()
+    assert ctx.render(pod, color, raw, count, color.size, opts, _ffi.SYNC_UPLOAD_SUMS, st) == 0     # sums stay on the device
+    H = cam.initialize().image_height
+    assert st.samples == 4 * W * H and (color[:W * H] != 0xDEADBEEF).all() and not raw.any() and not count.any()
+    opts.sample_offset = 4
+    assert ctx.render(pod, color, raw, count, color.size, opts, _ffi.SYNC_DOWNLOAD_SUMS, st) == 0   # ... and come back now
+    assert (count[:W * H] == 8).all()
+    cam8 = dray.camera_final(width=W, spp=8, depth=8)
+    cam8.mode, cam8.seed = dray.MODE_F32, 3
+    ref = fresh()
+    cam8.render(world, None, *ref)
+    assert (ref[0] == color).all() and (ref[1] == raw).all() and (ref[2] == count).all()
+    # another frame size without an upload is refused; another world makes the context rebuild its scenes
+    pod.image_width = 64
+    assert ctx.render(pod, color, raw, count, color.size, opts, 0, st) == _ffi.ERR_INVALID_ARG
+    ctx.set_scene(dray.scene_three_spheres())
+    cam3 = dray.camera_three_spheres(width=W, spp=3, depth=6)
+    cam3.mode, cam3.context = dray.MODE_F64, ctx
+    a, b = fresh(), fresh()
+    cam3.render(dray.scene_three_spheres(), None, *a)
+    cam3.context = None
+    cam3.render(dray.scene_three_spheres(), None, *b)
+    assert all((x == y).all() for x, y in zip(a, b))
+    # without sum buffers only the colours are produced
+    only = np.zeros(W * W, np.uint32)
+    cam3.context = ctx
+    cam3.render(dray.scene_three_spheres(), None, only, None, None)
+    H3 = cam3.image_height
+    assert (only[:W * H3] == b[0][:W * H3]).all() and not only[W * H3:].any()
+    # registering memory the caller already has works or is refused cleanly (this pool's driver refuses it)
+    mine = fresh()
+    try:
+        ctx.pin(*mine)
+    except dray.DrayError as err:
+        assert err.status == _ffi.ERR_HIP
+    cam3.render(dray.scene_three_spheres(), None, *mine)
+    assert (mine[0] == b[0]).all() and (mine[1] == b[1]).all()
+    ctx.close()
+    with pytest.raises(dray.DrayError):
+        ctx.set_scene(world)
+    # dray_render keeps its set-up between calls too (same list: scene reused; another list: rebuilt), and lets go of it
+    L = _ffi.lib()
+    for k in range(3):
+        c1 = fresh()
+        cam.render(world if k != 1 else dray.scene_final(2), None, *c1)
+    L.dray_release_cache()
+    c2 = fresh()
+    cam.render(world, None, *c2)
+    assert all((x == y).all() for x, y in zip(c1, c2))
+    with pytest.raises(dray.DrayError) as e:
+        dray.RenderContext([1])      # this box has one GPU
+    assert e.value.status == _ffi.ERR_INVALID_ARG
+
+
 def test_bounding_box_as_a_hittable(dray, gpu, oracle):
     """BoundingBox entries in the hittable list (bounding_box.rs:50-76 as written: two axes, `min - origin /
     direction`, Transparent material).  Boxes at the front, in the middle and at the end of the final scene's list:

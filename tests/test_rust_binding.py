@@ -170,7 +170,7 @@ def test_sys_crate_matches_header(tmp_path):
     r_structs, r_opaque, r_consts, r_funcs = parse_lib_rs()
     # structs: same set, same field names in the same order, same types
     assert set(c_structs) == set(r_structs), set(c_structs) ^ set(r_structs)
-    assert c_opaque == r_opaque == {"dray_scene"}
+    assert c_opaque == r_opaque == {"dray_scene", "dray_context"}
     for name, fields in c_structs.items():
         assert fields == r_structs[name], (name, fields, r_structs[name])
     # layout: the repr(C) rules applied to the Rust declarations give gcc's sizes and offsets
