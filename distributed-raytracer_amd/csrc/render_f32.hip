@@ -740,8 +740,9 @@ __device__ __forceinline__ void render_f32_body() {
         if (a->no_refill != 0 && __ballot(stage > 0) != 0ull) want = 0ull;
         while (want != 0ull) {
             const uint32_t W = (uint32_t)a->cam.W, spp = (uint32_t)a->cam.spp;
-            // at least one sample per lane in a pixel and rows longer than a pool: a hand-out wraps at most once
-            const bool stepwise = spp >= 64u && W >= (uint32_t)kSlots;
+            // a hand-out of at most 64 samples crosses at most 64 / spp pixels (stepped over one by one, cheaper than
+            // two integer divisions per lane down to 8 samples per pixel) and, with rows longer than a pool, one row end
+            const bool stepwise = spp >= 8u && W >= (uint32_t)kSlots;
             if (pool_q == pool_n && !exhausted) { // open the next pool
                 const uint32_t npix = pixel_count(), pixels_per_pool = (uint32_t)a->pixels_per_pool;
                 if (grab_next == grab_end) {
@@ -788,10 +789,10 @@ __device__ __forceinline__ void render_f32_body() {
             if (need && rank < take) {
                 // the lane's place in the pool: pixel `dp` places after the pool's first, sample `smp` of it
                 uint32_t dp, smp, r, i;
-                if (stepwise) { // one conditional step each instead of two integer divisions per hand-out
+                if (stepwise) { // a few conditional steps instead of two integer divisions per hand-out
                     smp = pool_smp + rank;
                     dp = pool_dp;
-                    if (smp >= spp) { smp -= spp; dp++; }
+                    while (smp >= spp) { smp -= spp; dp++; }
                     i = pool_i0 + dp;
                     r = pool_r0;
                     if (i >= W) { i -= W; r++; }
@@ -812,7 +813,7 @@ __device__ __forceinline__ void render_f32_body() {
             }
             pool_q += take;
             pool_smp += take;
-            if (pool_smp >= spp) { pool_smp -= spp; pool_dp++; } // only read when stepwise
+            while (pool_smp >= spp) { pool_smp -= spp; pool_dp++; } // only read when stepwise
             want = __ballot(need);
         }
         if (__ballot(stage > 0 || camera) == 0ull) break;
