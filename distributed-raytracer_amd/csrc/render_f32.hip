@@ -653,6 +653,27 @@ __device__ __forceinline__ void render_f32_body() {
             const float tmin = ray.tmin;
             float best = sb.t;
             // Re-evaluate the winner from the perpendicular remainder |oc - h d|, which does not cancel.
+#ifdef DRAY_F64_WINNER
+            // Experiment (tools/build_f64_winner_lib.sh): root, point and normal of the winning narrow sphere in f64 from
+            // the f32 ray.  Measured on the headline frame against the f64 kernel: see the design notes; not kept.
+            if (sb.pos >= 0) {
+                bidx = as_constant(a->narrow_index)[sb.pos];
+                ConstPtr<double> g64 = as_constant(a->geom64);
+                const double cx = g64[4 * bidx], cy = g64[4 * bidx + 1], cz = g64[4 * bidx + 2], rad = g64[4 * bidx + 3];
+                const double ocx = cx - (double)ox, ocy = cy - (double)oy, ocz = cz - (double)oz;
+                const double ddx = dx, ddy = dy, ddz = dz;
+                const double aa = fma(ddz, ddz, fma(ddy, ddy, ddx * ddx));
+                const double h = fma(ddz, ocz, fma(ddy, ocy, ddx * ocx));
+                const double cc = fma(ocz, ocz, fma(ocy, ocy, fma(ocx, ocx, -(rad * rad))));
+                const double disc = fmax(fma(h, h, -(aa * cc)), 0.);
+                const double sq = sqrt(disc);
+                const double t = (sb.far ? h + sq : h - sq) / aa;
+                best = (float)t;
+                const double px = fma(t, ddx, (double)ox), py = fma(t, ddy, (double)oy), pz = fma(t, ddz, (double)oz);
+                hp = {(float)px, (float)py, (float)pz};
+                hn = {(float)((px - cx) / rad), (float)((py - cy) / rad), (float)((pz - cz) / rad)};
+            }
+#else
             if (sb.pos >= 0) {
                 bidx = as_constant(a->narrow_index)[sb.pos];
                 const V4 s = as_constant(a->geom32)[bidx];
@@ -666,6 +687,7 @@ __device__ __forceinline__ void render_f32_body() {
                 const float ir = rcp(s.w);
                 hn = {(hp.x - s.x) * ir, (hp.y - s.y) * ir, (hp.z - s.z) * ir}; // sphere.rs:52
             }
+#endif
             const int32_t n_wide = a->n_wide;
             ConstPtr<int32_t> wide_index = as_constant(a->wide_index);
             ConstPtr<double> geom64 = as_constant(a->geom64);
