@@ -27,6 +27,9 @@ struct dray_scene {
     DeviceCounters* d_counters = nullptr;
     unsigned long long* d_accum = nullptr; // fixed-point colour sums of the f32 kernel
     size_t accum_capacity = 0;             // in u64 words
+    void* d_rings = nullptr;               // the f64 stream kernel's rings of finished samples (one per resident wave)
+    size_t rings_bytes = 0;
+    uint32_t ring_launches = 0;            // launches that have used the rings: entries are tagged with their launch
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     // The counters, the sums and the events are one set per scene, so a scene serves one call at a time: host
     // threads take `mu` for the length of a call, and a call enqueued on another stream than the one before it
@@ -171,7 +174,7 @@ void scene_free(dray_scene* s) {
     (void)hipFree(d.narrow_index); (void)hipFree(d.wide_index);
     (void)hipFree(d.grid_cells); (void)hipFree(d.grid_entry_geom); (void)hipFree(d.grid_entry_pos); (void)hipFree(d.grid_loose);
     (void)hipFree(d.box64); (void)hipFree(d.box_index);
-    (void)hipFree(s->d_counters); (void)hipFree(s->d_accum);
+    (void)hipFree(s->d_counters); (void)hipFree(s->d_accum); (void)hipFree(s->d_rings);
     for (auto& e : s->ev)
         if (e) (void)hipEventDestroy(e);
     delete s;
@@ -697,9 +700,38 @@ struct RenderJob {
             HIP_TRY(hipEventRecord(scene->ev[2], stream));
         } else {
             HIP_TRY(hipEventRecord(scene->ev[0], stream));
-            if (opts.mode == DRAY_MODE_F64)
-                HIP_TRY(launch_render_ref_f64(make_cam<double>(*cam, dv), scene->dev, part, key, opts.flags,
-                                              opts.variant != DRAY_SCAN_SCALAR, d_color, d_raw, d_count, d_counters, stream));
+            if (opts.mode == DRAY_MODE_F64) {
+                const CamDev<double> c = make_cam<double>(*cam, dv);
+                // Three organisations, one result: every sphere of the list per ray, one thread per pixel (scalar); the
+                // grid walk, one thread per pixel (hybrid); the grid walk as a stream of samples (auto, grid), which
+                // keeps finished samples in rings of its own -- so the entry point that may not allocate runs by pixel
+                int how = opts.variant == DRAY_SCAN_SCALAR ? kRefWholeList
+                          : (opts.variant == DRAY_SCAN_HYBRID || noalloc) ? kRefGridByPixel : kRefGridAsStream;
+                F64StreamPlan sp{};
+                if (how == kRefGridAsStream && !plan_render_f64_stream(c, part, scene->dev, scene->device, &sp)) how = kRefGridByPixel;
+                if (how == kRefGridAsStream) {
+                    if (sp.ring_bytes > scene->rings_bytes) {
+                        if (scene->d_rings) HIP_TRY(hipFree(scene->d_rings));
+                        scene->d_rings = nullptr;
+                        scene->rings_bytes = 0;
+                        HIP_TRY(hipMalloc(&scene->d_rings, sp.ring_bytes));
+                        // tag 0: written by no launch.  On the launch's own stream: a clear queued anywhere else could
+                        // still be running when the kernel writes its first tags, and wipe them
+                        HIP_TRY(hipMemsetAsync(scene->d_rings, 0, sp.ring_bytes, stream));
+                        scene->rings_bytes = sp.ring_bytes;
+                        scene->ring_launches = 0;
+                    }
+                    if (++scene->ring_launches == 0u) { // the launch number has wrapped: forget every old tag
+                        HIP_TRY(hipMemsetAsync(scene->d_rings, 0, scene->rings_bytes, stream));
+                        scene->ring_launches = 1u;
+                    }
+                    HIP_TRY(launch_render_f64_stream(c, scene->dev, part, key, opts.flags, sp, d_color, d_raw, d_count,
+                                                     d_counters, scene->d_rings, scene->ring_launches, stream));
+                } else {
+                    HIP_TRY(launch_render_ref_f64(c, scene->dev, part, key, opts.flags, how, d_color, d_raw, d_count,
+                                                  d_counters, stream));
+                }
+            }
             else
                 HIP_TRY(launch_render_ref_f32(make_cam<float>(*cam, dv), scene->dev, part, key, opts.flags, d_color, d_raw,
                                               d_count, d_counters, stream));

@@ -108,10 +108,31 @@ struct DeviceCounters {
 };
 
 // render_ref.hip
-// use_grid: find the closest hit by walking the scene's uniform grid instead of scanning the whole list (same result)
+// How the f64 render finds a ray's closest hit and how it runs its lanes; the results are the same bit for bit.
+enum {
+    kRefWholeList = 0,   // every sphere of the list, one thread per pixel on its own (DRAY_SCAN_SCALAR)
+    kRefGridByPixel = 1, // walk through the scene's uniform grid, one thread per pixel on its own (DRAY_SCAN_HYBRID)
+    kRefGridAsStream = 2 // the same walk, the frame run as a stream of samples (DRAY_SCAN_AUTO, DRAY_SCAN_GRID)
+};
 hipError_t launch_render_ref_f64(const CamDev<double>& cam, const SceneDev& scene, const Partition& part,
-                                 const RngKey& key, uint32_t flags, bool use_grid, uint32_t* d_color, double* d_raw,
+                                 const RngKey& key, uint32_t flags, int closest_hit, uint32_t* d_color, double* d_raw,
                                  int32_t* d_count, DeviceCounters* d_counters, hipStream_t stream);
+// The f64 render as a stream of samples: one persistent launch whose waves keep finished samples in rings of
+// kF64RingEntries 32-byte entries each until they join their pixel's sum in sample order.
+constexpr uint32_t kF64RingEntries = 2048;
+struct F64StreamPlan {
+    int32_t grid, block;   // resident blocks of the persistent launch
+    size_t ring_bytes;     // one ring per wave of the launch
+    uint32_t chunk_pixels; // consecutive pixels a wave takes from the queue at a time
+};
+// false: this frame or scene is not for the stream kernel (no grid over the scene, no samples)
+bool plan_render_f64_stream(const CamDev<double>& cam, const Partition& part, const SceneDev& scene, int device,
+                            F64StreamPlan* plan);
+// `rings`: plan.ring_bytes of device memory, zero before its first use; `launch_number`: 1, 2, ... per use of that memory
+hipError_t launch_render_f64_stream(const CamDev<double>& cam, const SceneDev& scene, const Partition& part,
+                                    const RngKey& key, uint32_t flags, const F64StreamPlan& plan, uint32_t* d_color,
+                                    double* d_raw, int32_t* d_count, DeviceCounters* d_counters, void* rings,
+                                    uint32_t launch_number, hipStream_t stream);
 hipError_t launch_render_ref_f32(const CamDev<float>& cam, const SceneDev& scene, const Partition& part,
                                  const RngKey& key, uint32_t flags, uint32_t* d_color, double* d_raw, int32_t* d_count,
                                  DeviceCounters* d_counters, hipStream_t stream);

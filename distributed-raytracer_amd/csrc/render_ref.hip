@@ -7,6 +7,8 @@
 // in the same order; pixels do not interact).
 #pragma clang fp contract(off)
 
+#include <mutex>
+
 #include "dray_device.h"
 #include "dray_internal.h"
 
@@ -50,17 +52,29 @@ template <> __device__ __forceinline__ double tiny_len2<double>() { return 1e-16
 template <> __device__ __forceinline__ float tiny_len2<float>() { return 1e-30f; }   // f32 stand-in for 1e-160
 
 // vec3.rs:76-84.  Attempt a uses uniforms 4a, 4a+1, 4a+2 of the stage = words 0..2 of block a.
+// One attempt: the point in the cube, its squared length, and whether the reference would keep it (:80).
+template <typename T> __device__ __forceinline__ bool unit_vector_attempt(const uint32_t (&w)[4], V3<T>& p, T& lensq) {
+    p.x = (T)-1. + ((T)1. - (T)-1.) * u01<T>(w[0]); // prelude.rs:27-30
+    p.y = (T)-1. + ((T)1. - (T)-1.) * u01<T>(w[1]);
+    p.z = (T)-1. + ((T)1. - (T)-1.) * u01<T>(w[2]);
+    lensq = vlen2(p);
+    return tiny_len2<T>() <= lensq && lensq <= (T)1.;
+}
 template <typename T> __device__ __forceinline__ V3<T> random_unit_vector(const Stream& st) {
     for (uint32_t a = 0;; ++a) {
         uint32_t w[4];
         st.block(a, w);
         V3<T> p;
-        p.x = (T)-1. + ((T)1. - (T)-1.) * u01<T>(w[0]); // prelude.rs:27-30
-        p.y = (T)-1. + ((T)1. - (T)-1.) * u01<T>(w[1]);
-        p.z = (T)-1. + ((T)1. - (T)-1.) * u01<T>(w[2]);
-        T lensq = vlen2(p);
-        if (tiny_len2<T>() <= lensq && lensq <= (T)1.) return vdiv(p, vsqrt(lensq));
+        T lensq;
+        if (unit_vector_attempt<T>(w, p, lensq)) return vdiv(p, vsqrt(lensq));
     }
+}
+
+// vec3.rs:111-118, one attempt: two consecutive uniforms of stage 0.
+template <typename T> __device__ __forceinline__ bool unit_disk_attempt(uint32_t wx, uint32_t wy, T& px, T& py) {
+    px = (T)-1. + ((T)1. - (T)-1.) * u01<T>(wx);
+    py = (T)-1. + ((T)1. - (T)-1.) * u01<T>(wy);
+    return px * px + py * py + (T)0. * (T)0. < (T)1.;
 }
 
 template <typename T> struct Hit {
@@ -286,17 +300,20 @@ template <typename T> __device__ __forceinline__ T reflectance(T cosine, T ri) {
 }
 
 // material.rs scatter of the five material kinds.  Returns false when the ray is absorbed.  `so` comes in as the
-// incoming ray's origin and goes out as the scattered ray's: the hit point, except for Transparent.
-template <typename T>
-__device__ __forceinline__ bool scatter(uint32_t kind, const T* __restrict__ mat, V3<T> rd, const Hit<T>& rec,
-                                        const Stream& st, V3<T>& so, V3<T>& sd) {
+// incoming ray's origin and goes out as the scattered ray's: the hit point, except for Transparent.  The two random
+// draws a scatter may make come through callables: `unit_vector()` is random_unit_vector (vec3.rs:76-84),
+// `uniform()` the dielectric's random_f64 (material.rs:114); each is called at most once, and only where the
+// reference draws.
+template <typename T, typename UnitVector, typename Uniform>
+__device__ __forceinline__ bool scatter_with(uint32_t kind, const T* __restrict__ mat, V3<T> rd, const Hit<T>& rec,
+                                             UnitVector&& unit_vector, Uniform&& uniform, V3<T>& so, V3<T>& sd) {
     if (kind == DRAY_MAT_TRANSPARENT) { // material.rs:25-31: the incoming ray, unchanged
         sd = rd;
         return true;
     }
     so = rec.p;
     if (kind == DRAY_MAT_LAMBERTIAN) { // material.rs:46-56
-        V3<T> dir = vadd(rec.normal, random_unit_vector<T>(st));
+        V3<T> dir = vadd(rec.normal, unit_vector());
         const T s = (T)1e-8; // vec3.rs:42-45
         if (fabs(dir.x) < s && fabs(dir.y) < s && fabs(dir.z) < s) dir = rec.normal;
         sd = dir;
@@ -304,7 +321,7 @@ __device__ __forceinline__ bool scatter(uint32_t kind, const T* __restrict__ mat
     }
     if (kind == DRAY_MAT_METAL) { // material.rs:73-80
         V3<T> refl = reflect(rd, rec.normal);
-        refl = vadd(vunit(refl), vscale(random_unit_vector<T>(st), mat[3]));
+        refl = vadd(vunit(refl), vscale(unit_vector(), mat[3]));
         sd = refl;
         return vdot(sd, rec.normal) > (T)0.;
     }
@@ -315,23 +332,33 @@ __device__ __forceinline__ bool scatter(uint32_t kind, const T* __restrict__ mat
         T cos_theta = fmin(vdot(vneg(ud), rec.normal), (T)1.0);
         T sin_theta = vsqrt((T)1.0 - cos_theta * cos_theta);
         bool reflects = ri * sin_theta > (T)1.0;
-        if (!reflects) { // the uniform is drawn only when refraction is possible
-            uint32_t w[4];
-            st.block(0, w);
-            reflects = reflectance(cos_theta, ri) > u01<T>(w[0]);
-        }
+        if (!reflects) reflects = reflectance(cos_theta, ri) > uniform(); // drawn only when refraction is possible
         sd = reflects ? reflect(ud, rec.normal) : refract(ud, rec.normal, ri);
         return true;
     }
     return false; // material.rs:13-19
 }
 
-// camera.rs:238-262
+// The same with the draws made on the spot from the stage's stream: the unit vector's attempts are blocks 0, 1, ...,
+// the dielectric's uniform is word 0 of block 0.
 template <typename T>
-__device__ __forceinline__ void get_ray(const CamDev<T>& cam, int32_t i, int32_t j, const Stream& st, V3<T>& ro,
-                                        V3<T>& rd) {
-    uint32_t w[4];
-    st.block(0, w);
+__device__ __forceinline__ bool scatter(uint32_t kind, const T* __restrict__ mat, V3<T> rd, const Hit<T>& rec,
+                                        const Stream& st, V3<T>& so, V3<T>& sd) {
+    return scatter_with<T>(
+        kind, mat, rd, rec, [&]() { return random_unit_vector<T>(st); },
+        [&]() {
+            uint32_t w[4];
+            st.block(0, w);
+            return u01<T>(w[0]);
+        },
+        so, sd);
+}
+
+// camera.rs:238-262 from the draws already made: `w` = block 0 of the sample's stage-0 stream (uniforms 0, 1 are the
+// offsets in the pixel), (px, py) = the accepted point of random_in_unit_disk (read only with defocus).
+template <typename T>
+__device__ __forceinline__ void get_ray_with(const CamDev<T>& cam, int32_t i, int32_t j, const uint32_t (&w)[4], T px, T py,
+                                             V3<T>& ro, V3<T>& rd) {
     const T ox = u01<T>(w[0]) - (T)0.5, oy = u01<T>(w[1]) - (T)0.5;
     const V3<T> p00 = {cam.p00[0], cam.p00[1], cam.p00[2]};
     const V3<T> du = {cam.du[0], cam.du[1], cam.du[2]}, dv = {cam.dv[0], cam.dv[1], cam.dv[2]};
@@ -340,19 +367,29 @@ __device__ __forceinline__ void get_ray(const CamDev<T>& cam, int32_t i, int32_t
     if (!cam.defocus) {
         ro = center;
     } else {
-        // vec3.rs:111-118; attempt m uses uniforms 2+2m, 3+2m of stage 0
-        T px, py;
-        for (uint32_t m = 0;; ++m) {
-            const uint32_t d0 = 2u + 2u * m;
-            if (m > 0 && (d0 & 3u) == 0u) st.block(d0 >> 2, w);
-            px = (T)-1. + ((T)1. - (T)-1.) * u01<T>(w[d0 & 3u]);
-            py = (T)-1. + ((T)1. - (T)-1.) * u01<T>(w[(d0 & 3u) + 1u]);
-            if (px * px + py * py + (T)0. * (T)0. < (T)1.) break;
-        }
         const V3<T> ddu = {cam.ddu[0], cam.ddu[1], cam.ddu[2]}, ddv = {cam.ddv[0], cam.ddv[1], cam.ddv[2]};
         ro = vadd(vadd(center, vscale(ddu, px)), vscale(ddv, py));
     }
     rd = vsub(ps, ro);
+}
+
+// camera.rs:238-262 with the draws made on the spot
+template <typename T>
+__device__ __forceinline__ void get_ray(const CamDev<T>& cam, int32_t i, int32_t j, const Stream& st, V3<T>& ro,
+                                        V3<T>& rd) {
+    uint32_t w0[4], w[4];
+    st.block(0, w0);
+    T px = (T)0., py = (T)0.;
+    if (cam.defocus) {
+        // vec3.rs:111-118; attempt m uses uniforms 2+2m, 3+2m of stage 0
+        w[0] = w0[0]; w[1] = w0[1]; w[2] = w0[2]; w[3] = w0[3];
+        for (uint32_t m = 0;; ++m) {
+            const uint32_t d0 = 2u + 2u * m;
+            if (m > 0 && (d0 & 3u) == 0u) st.block(d0 >> 2, w);
+            if (unit_disk_attempt<T>(w[d0 & 3u], w[(d0 & 3u) + 1u], px, py)) break;
+        }
+    }
+    get_ray_with<T>(cam, i, j, w0, px, py, ro, rd);
 }
 
 template <typename T>
@@ -458,6 +495,463 @@ __global__ __launch_bounds__(256) void render_ref_kernel(CamDev<T> cam, const T*
     }
 }
 
+// ---- the f64 render as a stream of samples -----------------------------------------------------------------
+//
+// render_ref_kernel above gives every pixel a thread that runs the pixel's loop on its own.  Its lanes wait for each
+// other wherever their trip counts differ -- the grid walk (one to dozens of cells), a cell's sphere list, the
+// rejection samplers -- and a wave lives as long as its dearest pixel takes for all of its samples, so that the
+// machine is half empty for much of a launch.  The kernel below computes the same values and adds them in the same
+// order, organised like the f32 throughput kernel (render_f32.hip):
+//   * one persistent launch; a wave draws chunks of consecutive pixels from a global queue and hands their samples,
+//     in order, to whichever of its lanes is free: a lane carries one sample's path;
+//   * a lane's walk through the grid is kept in registers across turns of the main loop; the wave takes walk steps
+//     (one action per lane and step: leave a cell, or test one listed sphere) only while enough lanes are walking,
+//     then the lanes whose walk is over are shaded and given their next ray while the long walks go on;
+//   * the two rejection samplers (vec3.rs:76-84, 111-118) are evaluated by the whole wave: lanes whose first attempt
+//     failed hand their stream to server lanes, which try the following blocks in parallel; the lane takes the
+//     accepted attempt with the smallest index -- the one its own loop would have stopped at;
+//   * the first Philox block of new samples and of the scattering lanes' stage is one evaluation.
+// Samples end out of order, and f64 sums depend on the order (colors.rs:38 adds a pixel's samples one after the
+// other), so a finished sample's colour goes into the wave's ring in memory, at the place of its number in the
+// wave's stream, and the wave retires the ring in stream order: the pixel's running sum takes the colours of
+// samples 0, 1, 2, ... exactly as the per-pixel loop does.  A lane may not take a sample more than a ring's length
+// ahead of the oldest unfinished one.
+// Closest hit: as list_hit_grid (minimum over (root, list position) of sphere_root's roots over the wide, the loose
+// and the walked spheres).  A ray that is not finite, or a walk that outlasts a straight line, takes the scan of
+// the whole list, as there.
+
+enum { kDraw64None = 0, kDraw64UnitVector = 1, kDraw64UnitDisk = 2 };
+#ifndef DRAY_F64_WALK_QUORUM
+#define DRAY_F64_WALK_QUORUM 16
+#endif
+
+struct Drawn {
+    uint32_t a, b, c; // the accepted attempt's words: a unit vector's three, or a disk point's two
+};
+
+// Both rejection samplers for all lanes of a wave (wave-uniform control flow; every lane calls).  `w` is block 0 of
+// the lane's stream, `draw` what the lane needs.  Acceptance is decided in f64 with the reference's expressions.
+__device__ __forceinline__ Drawn coop_draw64(const Stream& st, const uint32_t (&w)[4], uint32_t draw, uint4* req, int lane) {
+    Drawn res = {w[0], w[1], w[2]};
+    bool pending = false;
+    V3<double> p;
+    double l2, qx, qy;
+    if (draw == kDraw64UnitVector) {
+        pending = !unit_vector_attempt<double>(w, p, l2);
+    } else if (draw == kDraw64UnitDisk) { // attempt 0 of the aperture sample: uniforms 2, 3 of stage 0
+        res = {w[2], w[3], 0u};
+        pending = !unit_disk_attempt<double>(w[2], w[3], qx, qy);
+    }
+    uint32_t base = 1u; // next block index, the same for every pending lane
+    for (unsigned long long pm = __ballot(pending); pm != 0ull; pm = __ballot(pending)) {
+        const uint32_t n_pending = (uint32_t)__popcll(pm);
+        const uint32_t shift = n_pending <= 8u ? 3u : n_pending <= 16u ? 2u : n_pending <= 32u ? 1u : 0u; // log2 servers per lane
+        const uint32_t rank = (uint32_t)__popcll(pm & ((1ull << lane) - 1ull));
+        if (pending) req[rank] = make_uint4(st.pixel, st.sample, st.stage, draw);
+        const uint32_t served = (uint32_t)lane >> shift;
+        const bool serving = served < n_pending;
+        const uint4 r = req[serving ? served : 0u];
+        const Stream other = {st.k0, st.k1, r.x, r.y, r.z};
+        uint32_t wb[4];
+        other.block(base + ((uint32_t)lane & ((1u << shift) - 1u)), wb);
+        const bool ok_vector = unit_vector_attempt<double>(wb, p, l2);
+        // a block after the first holds two aperture attempts: uniforms 4b, 4b+1 and 4b+2, 4b+3
+        const bool ok_a = unit_disk_attempt<double>(wb[0], wb[1], qx, qy), ok_b = unit_disk_attempt<double>(wb[2], wb[3], qx, qy);
+        const bool disk = r.w == kDraw64UnitDisk;
+        const uint32_t va = disk ? (ok_a ? wb[0] : wb[2]) : wb[0], vb = disk ? (ok_a ? wb[1] : wb[3]) : wb[1], vc = wb[2];
+        const bool ok = serving & (disk ? (ok_a | ok_b) : ok_vector);
+        const unsigned long long okm = __ballot(ok);
+        const uint32_t first = pending ? (rank << shift) : 0u; // my first server lane
+        const uint32_t mine = (uint32_t)(okm >> first) & ((1u << (1u << shift)) - 1u);
+        const bool got = pending & (mine != 0u);
+        const int from = got ? (int)(first + (uint32_t)__builtin_ctz(mine)) : lane;
+        const uint32_t ga = __shfl(va, from, 64), gb = __shfl(vb, from, 64), gc = __shfl(vc, from, 64);
+        if (got) {
+            res = {ga, gb, gc};
+            pending = false;
+        }
+        base += 1u << shift;
+    }
+    return res;
+}
+
+// A lane's walk through the grid, kept across turns of the main loop.
+struct Walk64 {
+    double A[3], B[3]; // time at which the ray leaves cell k of an axis: k * A + B
+    double slack;
+    int32_t c[3];      // current cell
+    uint32_t e, e_end; // entries of the current cell still to test
+    int32_t steps;
+    double closest;    // smallest accepted root so far, and its sphere's list position
+    int32_t best;
+};
+
+__device__ __forceinline__ void test64(const double* __restrict__ geom, int32_t k, V3<double> ro, V3<double> rd,
+                                       Walk64& w) {
+    double root;
+    if (sphere_root<double>(geom, k, ro, rd, root) && (root < w.closest || (root == w.closest && k < w.best))) {
+        w.closest = root;
+        w.best = k;
+    }
+}
+
+// One finished sample in a wave's ring: the colour that joins the pixel's sum (camera.rs:223-225: 0 + sample), and
+// which sample of which launch wrote it.
+struct RingEntry {
+    double r, g, b;
+    unsigned long long tag; // launch number << 32 | the sample's number in the wave's stream + 1
+};
+static_assert(sizeof(RingEntry) == 32, "a ring entry is two 16-byte stores");
+constexpr uint32_t kFifoSlots = 16; // chunks a wave may have grabbed and not begun to retire
+
+#ifndef DRAY_F64_WAVES_PER_EU
+#define DRAY_F64_WAVES_PER_EU 3
+#endif
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DRAY_F64_WAVES_PER_EU, DRAY_F64_WAVES_PER_EU)))
+void render_f64_stream_kernel(CamDev<double> cam, const double* __restrict__ geom, const double* __restrict__ mat,
+                              const uint32_t* __restrict__ kind, int32_t n, RefGrid rg, Partition part, RngKey key,
+                              uint32_t flags, uint32_t* __restrict__ color, double* __restrict__ raw,
+                              int32_t* __restrict__ count, DeviceCounters* counters, RingEntry* rings,
+                              uint32_t launch_number, uint32_t chunk_pixels) {
+    __shared__ uint4 lds_req[4][64];           // coop_draw64: streams handed to server lanes, one set of slots per wave
+    __shared__ uint32_t lds_fifo[4][kFifoSlots]; // first pixel of the chunks the wave has grabbed, oldest first
+    const int lane = (int)(threadIdx.x & 63u), wv = (int)(threadIdx.x >> 6);
+    const GridDev& g = rg.grid;
+    const uint32_t W = (uint32_t)cam.W, spp = (uint32_t)cam.spp, npix = (uint32_t)part.n_rows * W;
+    const bool iterative = (flags & DRAY_FLAG_ITERATIVE_PRODUCT) != 0;
+    RingEntry* ring = rings + (size_t)(blockIdx.x * 4u + (uint32_t)wv) * kF64RingEntries;
+    const unsigned long long tag_base = (unsigned long long)launch_number << 32;
+    const int32_t max_steps = g.n[0] + g.n[1] + g.n[2] + 4;
+    unsigned long long my_segments = 0;
+
+    // where partition pixel `pp` lives: its place in the caller's buffers and its Philox pixel word j * W + i
+    auto place_of = [&](uint32_t pp, size_t& out, uint32_t& word) {
+        const uint32_t r = pp / W, i = pp - r * W;
+        const uint32_t j = (uint32_t)part.row_begin + r * (uint32_t)part.row_step;
+        out = (size_t)(part.compact ? r : j) * (size_t)W + (size_t)i;
+        word = j * W + i;
+    };
+
+    // per-lane state: one sample's path
+    uint32_t stack[kExactMaxDepth]; // spheres whose albedo multiplies the sample, outermost first
+    V3<double> ro = {0., 0., 0.}, rd = {0., 0., 1.};
+    V3<double> att = {1., 1., 1.}; // camera.rs:26 (iterative form)
+    uint32_t pw = 0u, smp = 0u, item = 0u; // the sample: Philox pixel word, sample number, number in the wave's stream
+    int32_t depth = 0, sp = 0;
+    bool has = false;      // the lane carries a sample
+    bool camera = false;   // ... whose camera ray is still to be made
+    bool walking = false;  // on its way through the grid
+    bool dead = false;     // the path was absorbed: the sample ends black at the lane's next turn
+    bool fallback = false; // the closest hit of this ray comes from the scan of the whole list
+    Walk64 wk = {};
+    wk.closest = INFINITY;
+    wk.best = 0x7fffffff;
+
+    // wave state (the same in every lane)
+    uint32_t issued = 0u, retired = 0u;       // samples of the wave's stream handed out / added to their pixels
+    uint32_t grabbed = 0u, begun = 0u;        // chunks taken from the queue / chunks whose retirement has begun
+    uint32_t iss_p0 = 0u, iss_q = 0u, iss_n = 0u;     // the chunk being handed out: first pixel, next sample, samples
+    uint32_t ret_p0 = 0u, ret_dp = 0u, ret_np = 0u, ret_s = 0u; // the chunk being retired: first pixel, pixel, pixels; sample
+    size_t ret_out = 0;
+    double acc[3] = {0., 0., 0.};             // running sum of the pixel being retired
+    unsigned long long n_samples = 0ull;
+    bool exhausted = false;
+
+    for (;;) {
+        // ---- walk steps, while enough lanes are on their way --------------------------------------------------
+        {
+            const int quorum = exhausted ? 1 : DRAY_F64_WALK_QUORUM;
+            do { // at least one step a turn: fewer lanes than a quorum may be all the wave has
+                if (walking) {
+                    if (wk.e == wk.e_end) { // this cell is done: stop, or step into the next one
+                        const double tx = (double)wk.c[0] * wk.A[0] + wk.B[0], ty = (double)wk.c[1] * wk.A[1] + wk.B[1],
+                                     tz = (double)wk.c[2] * wk.A[2] + wk.B[2];
+                        const double t_exit = fmin(tx, fmin(ty, tz));
+                        const bool stop = wk.closest < t_exit * (1. - 1e-9) - wk.slack; // nothing beyond this cell can be closer
+                        const int ax = (tx <= ty && tx <= tz) ? 0 : (ty <= tz ? 1 : 2);
+                        const double Aax = ax == 0 ? wk.A[0] : (ax == 1 ? wk.A[1] : wk.A[2]);
+                        const int32_t dir = Aax < 0. ? -1 : 1;
+                        wk.c[0] += ax == 0 ? dir : 0;
+                        wk.c[1] += ax == 1 ? dir : 0;
+                        wk.c[2] += ax == 2 ? dir : 0;
+                        const int32_t moved = ax == 0 ? wk.c[0] : (ax == 1 ? wk.c[1] : wk.c[2]);
+                        const int32_t limit = ax == 0 ? g.n[0] : (ax == 1 ? g.n[1] : g.n[2]);
+                        const bool inside = moved >= 0 && moved < limit;
+                        bool go = inside && !stop;
+                        if (go && ++wk.steps > max_steps) { // cannot happen on a straight line: take the whole list
+                            fallback = true;
+                            go = false;
+                        }
+                        walking = go;
+                        const uint2 cellrec = g.cells[go ? ((size_t)wk.c[2] * g.n[1] + wk.c[1]) * g.n[0] + wk.c[0] : 0];
+                        wk.e = cellrec.x;
+                        wk.e_end = go ? cellrec.x + cellrec.y : cellrec.x;
+                    }
+                    if (wk.e != wk.e_end) {
+                        test64(geom, rg.narrow_index[g.entry_pos[wk.e]], ro, rd, wk);
+                        ++wk.e;
+                    }
+                }
+            } while (__popcll(__ballot(walking)) >= quorum);
+        }
+
+        // ---- lanes whose walk is over: the hit (hittable_list.rs:60-74 / sphere.rs:49-55), or the sky -----------
+        const bool ready = has && !walking && !camera;
+        Hit<double> rec = {};
+        bool scatters = false, ended = false;
+        uint32_t mk = 0xFFu;
+        V3<double> c = {0., 0., 0.};
+        if (ready) {
+            if (depth <= 0 || dead) { // camera.rs:265-267 / :120-123, or absorbed (camera.rs:276): black
+                ended = true;
+            } else {
+                bool hit;
+                if (fallback) {
+                    hit = list_hit_linear<double>(geom, n, rg, ro, rd, rec);
+                } else if (boxes_hit<double>(rg, ro, rd, wk.closest, wk.best, rec)) {
+                    hit = true;
+                } else if (wk.best == 0x7fffffff) {
+                    hit = false;
+                } else {
+                    fill_hit<double>(geom, wk.best, ro, rd, wk.closest, rec);
+                    hit = true;
+                }
+                if (hit) {
+                    mk = kind[rec.index];
+                    scatters = true;
+                } else {
+                    V3<double> ud = vunit(rd); // camera.rs:279-281
+                    double a = 0.5 * (ud.y + 1.0);
+                    c = vadd(vscale(V3<double>{1.0, 1.0, 1.0}, 1.0 - a), vscale(V3<double>{0.5, 0.7, 1.0}, a));
+                    ended = true;
+                }
+            }
+        }
+
+        // ---- samples that end here: their colour goes to its place in the wave's ring ---------------------------
+        if (ended) {
+            if (iterative) {
+                c = vmul(att, c); // camera.rs:121,135,142
+            } else {
+                while (sp > 0) { // camera.rs:274, innermost product first
+                    const uint32_t q = stack[--sp];
+                    c = vmul(V3<double>{mat[4 * q], mat[4 * q + 1], mat[4 * q + 2]}, c);
+                }
+            }
+            RingEntry* e = ring + (item & (kF64RingEntries - 1u));
+            e->r = 0. + c.x; // camera.rs:223-225: pixel_color = (0, 0, 0) + sample
+            e->g = 0. + c.y;
+            e->b = 0. + c.z;
+            e->tag = tag_base | (unsigned long long)(item + 1u);
+            dead = false;
+            has = false;
+        }
+
+        // ---- retire: the ring's finished samples, in the order of the stream, join their pixels (colors.rs:38-43) ----
+        if (retired != issued) {
+            const uint32_t at = retired + (uint32_t)lane;
+            const RingEntry* e = ring + (at & (kF64RingEntries - 1u));
+            // (this wave wrote the entry, through the same cache: an earlier store is seen by this load)
+            const double er = e->r, eg = e->g, eb = e->b;
+            const bool ok = at - retired < issued - retired && e->tag == (tag_base | (unsigned long long)(at + 1u));
+            const unsigned long long okm = __ballot(ok);
+            const int n_ok = ~okm == 0ull ? 64 : __builtin_ctzll(~okm); // finished samples at the head of the stream
+            for (int k = 0; k < n_ok; ++k) {
+                if (ret_s == 0u) { // a pixel begins
+                    if (ret_dp == ret_np) { // ... and with it a chunk
+                        ret_p0 = lds_fifo[wv][begun & (kFifoSlots - 1u)];
+                        ret_np = min(chunk_pixels, npix - ret_p0);
+                        ret_dp = 0u;
+                        begun++;
+                    }
+                    uint32_t word;
+                    place_of(ret_p0 + ret_dp, ret_out, word);
+                    acc[0] = acc[1] = acc[2] = 0.;
+                    if (raw) { acc[0] = raw[3 * ret_out + 0]; acc[1] = raw[3 * ret_out + 1]; acc[2] = raw[3 * ret_out + 2]; }
+                }
+                acc[0] += __shfl(er, k, 64); // colors.rs:38
+                acc[1] += __shfl(eg, k, 64);
+                acc[2] += __shfl(eb, k, 64);
+                if (++ret_s == spp) { // the pixel is complete
+                    if (lane == 0) {
+                        const int32_t cnt = (count ? count[ret_out] : 0) + (int32_t)spp; // colors.rs:39
+                        const double denom = cnt != 0 ? (double)cnt : 1.;                 // colors.rs:40
+                        color[ret_out] = pack_argb(acc[0] / denom, acc[1] / denom, acc[2] / denom);
+                        if (raw) { raw[3 * ret_out + 0] = acc[0]; raw[3 * ret_out + 1] = acc[1]; raw[3 * ret_out + 2] = acc[2]; }
+                        if (count) count[ret_out] = cnt;
+                    }
+                    ret_s = 0u;
+                    ret_dp++;
+                }
+            }
+            retired += (uint32_t)n_ok;
+            n_samples += (unsigned long long)n_ok;
+        }
+
+        // ---- refill: free lanes take the next samples of the stream (camera.rs:217-224) ------------------------
+        {
+            bool need = !has;
+            unsigned long long want = __ballot(need);
+            while (want != 0ull) {
+                if (iss_q == iss_n && !exhausted) { // the next chunk of pixels
+                    if (grabbed - begun == kFifoSlots) break;
+                    unsigned long long base = 0ull;
+                    if (lane == 0) base = atomicAdd(&counters->next_item, (unsigned long long)chunk_pixels);
+                    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)base);
+                    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
+                    if (hi != 0u || lo >= npix) {
+                        exhausted = true;
+                    } else {
+                        if (lane == 0) lds_fifo[wv][grabbed & (kFifoSlots - 1u)] = lo;
+                        grabbed++;
+                        iss_p0 = lo;
+                        iss_q = 0u;
+                        iss_n = min(chunk_pixels, npix - lo) * spp;
+                    }
+                }
+                if (exhausted) break;
+                const uint32_t room = kF64RingEntries - (issued - retired); // a ring's length ahead of the oldest at most
+                const uint32_t avail = min(iss_n - iss_q, room);
+                const uint32_t wanted = (uint32_t)__popcll(want);
+                const uint32_t take = wanted < avail ? wanted : avail;
+                if (take == 0u) break;
+                const uint32_t rank = (uint32_t)__popcll(want & ((1ull << lane) - 1ull));
+                if (need && rank < take) {
+                    const uint32_t q = iss_q + rank;
+                    const uint32_t dp = q / spp;
+                    size_t out;
+                    place_of(iss_p0 + dp, out, pw);
+                    smp = q - dp * spp;
+                    item = issued + rank;
+                    has = true;
+                    camera = true;
+                    need = false;
+                }
+                iss_q += take;
+                issued += take;
+                want = __ballot(need);
+            }
+        }
+        if (__ballot(has) == 0ull && retired == issued) break; // nothing in flight, nothing left to take
+
+        // ---- the first uniforms of the next step, and the rejection samplers, by the whole wave -----------------
+        const bool draws = scatters || camera;
+        const Stream st = {key.k0, key.k1, pw, key.sample_offset + smp, camera ? 0u : (uint32_t)(cam.max_depth - depth + 1)};
+        uint32_t w[4] = {0u, 0u, 0u, 0u};
+        if (draws) st.block(0, w);
+        const uint32_t draw = (scatters && (mk == DRAY_MAT_LAMBERTIAN || mk == DRAY_MAT_METAL)) ? (uint32_t)kDraw64UnitVector
+                              : (camera && cam.defocus != 0)                                      ? (uint32_t)kDraw64UnitDisk
+                                                                                                  : (uint32_t)kDraw64None;
+        const Drawn got = coop_draw64(st, w, draw, lds_req[wv], lane);
+
+        // ---- scatter: material.rs -------------------------------------------------------------------------
+        bool fresh = false;
+        if (scatters) {
+            V3<double> so = ro, sd;
+            const bool scattered = scatter_with<double>(
+                mk, mat + 4 * rec.index, rd, rec,
+                [&]() { // vec3.rs:82 for the accepted attempt
+                    const uint32_t ww[4] = {got.a, got.b, got.c, 0u};
+                    V3<double> p;
+                    double lensq;
+                    unit_vector_attempt<double>(ww, p, lensq);
+                    return vdiv(p, vsqrt(lensq));
+                },
+                [&]() { return u01<double>(w[0]); }, so, sd);
+            if (scattered) {
+                const bool white = mk == DRAY_MAT_DIELECTRIC || mk == DRAY_MAT_TRANSPARENT; // attenuation (1, 1, 1)
+                if (iterative) {
+                    V3<double> al = white ? V3<double>{1., 1., 1.}
+                                          : V3<double>{mat[4 * rec.index], mat[4 * rec.index + 1], mat[4 * rec.index + 2]};
+                    att = vmul(att, al); // camera.rs:130
+                } else if (!white) {
+                    stack[sp++] = (uint32_t)rec.index; // a product with (1,1,1) is exact, so those are skipped
+                }
+                ro = so;
+                rd = sd;
+                depth -= 1;
+                fresh = depth > 0; // with no depth left the sample ends black at the lane's next turn
+            } else {
+                dead = true; // camera.rs:276
+            }
+        }
+
+        // ---- camera ray of a new sample: camera.rs:238-262 --------------------------------------------------
+        if (camera) {
+            double px = 0., py = 0.;
+            unit_disk_attempt<double>(got.a, got.b, px, py);
+            const uint32_t j = pw / W, i = pw - j * W;
+            get_ray_with<double>(cam, (int32_t)i, (int32_t)j, w, px, py, ro, rd);
+            att = {1., 1., 1.};
+            depth = cam.max_depth;
+            sp = 0;
+            camera = false;
+            fresh = depth > 0;
+        }
+
+        // ---- a new ray: the spheres every ray meets, then its first cell ------------------------------------------
+        if (fresh) {
+            my_segments++;
+            wk.closest = INFINITY;
+            wk.best = 0x7fffffff;
+            wk.e = wk.e_end = 0u;
+            wk.steps = 0;
+            fallback = false;
+            walking = false;
+            const double o[3] = {ro.x, ro.y, ro.z}, d[3] = {rd.x, rd.y, rd.z};
+            bool finite = true;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) finite = finite && fabs(o[a]) < 1e300 && fabs(d[a]) < 1e300; // false for NaN too
+            if (!finite) {
+                fallback = true;
+            } else {
+                for (int32_t q = 0; q < rg.n_wide; ++q) test64(geom, rg.wide_index[q], ro, rd, wk);
+                for (int32_t q = 0; q < g.n_loose; ++q) test64(geom, rg.narrow_index[g.loose[q]], ro, rd, wk);
+                if (g.n[0] > 0) {
+                    double t_in = 0., t_out = INFINITY, bmax = 0.;
+                    bool inside_slabs = true;
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) {
+                        if (fabs(d[a]) > 1e-250) {
+                            const double inv = 1.0 / d[a];
+                            wk.A[a] = (double)g.cell[a] * inv;
+                            const double t0 = ((double)g.lo[a] - o[a]) * inv, t1 = ((double)g.hi[a] - o[a]) * inv;
+                            wk.B[a] = d[a] >= 0. ? t0 + wk.A[a] : t0; // leaving cell k towards larger indices happens at plane k + 1
+                            t_in = fmax(t_in, fmin(t0, t1));
+                            t_out = fmin(t_out, fmax(t0, t1));
+                            bmax = fmax(bmax, fmax(fabs(t0), fabs(wk.B[a])));
+                        } else { // parallel to the axis' planes: never crosses one; misses the grid if outside its slab
+                            wk.A[a] = 0.;
+                            wk.B[a] = INFINITY;
+                            if (o[a] < (double)g.lo[a] || o[a] > (double)g.hi[a]) inside_slabs = false;
+                        }
+                    }
+                    wk.slack = bmax * 1e-9;
+                    if (inside_slabs && t_in <= t_out + wk.slack) {
+#pragma unroll
+                        for (int a = 0; a < 3; ++a) {
+                            const double at = floor((o[a] + d[a] * t_in - (double)g.lo[a]) * (double)g.inv_cell[a]);
+                            wk.c[a] = (int32_t)fmin(fmax(at, 0.), (double)(g.n[a] - 1));
+                        }
+                        const uint2 cellrec = g.cells[((size_t)wk.c[2] * g.n[1] + wk.c[1]) * g.n[0] + wk.c[0]];
+                        wk.e = cellrec.x;
+                        wk.e_end = cellrec.x + cellrec.y;
+                        walking = true;
+                    }
+                }
+            }
+        }
+    }
+
+    // one atomic per wave
+    for (int off = 32; off > 0; off >>= 1) my_segments += __shfl_down(my_segments, off, 64);
+    if (lane == 0 && counters) {
+        atomicAdd(&counters->segments, my_segments);
+        atomicAdd(&counters->samples, n_samples);
+    }
+}
+
 // CameraRayIterator::next (camera.rs:103-114) + RayColorEntry::new (camera.rs:23-31) for a list of pixel indices.
 __global__ __launch_bounds__(256) void camera_rays_kernel(CamDev<double> cam, RngKey key,
                                                           const dray_pixel_index* __restrict__ px, size_t n,
@@ -548,31 +1042,78 @@ RefGrid ref_grid_of(const SceneDev& scene, bool use) {
 
 template <typename T>
 hipError_t launch_ref(const CamDev<T>& cam, const T* geom, const T* mat, const SceneDev& scene, const Partition& part,
-                      const RngKey& key, uint32_t flags, bool use_grid, uint32_t* d_color, double* d_raw, int32_t* d_count,
+                      const RngKey& key, uint32_t flags, int closest_hit, uint32_t* d_color, double* d_raw, int32_t* d_count,
                       DeviceCounters* d_counters, hipStream_t stream) {
     const long long total = (long long)part.n_rows * cam.W;
     if (total <= 0) return hipSuccess;
     const int block = 256;
     const long long grid = (total + block - 1) / block;
     if (grid > 0x7fffffffLL) return hipErrorInvalidValue;
+    const RefGrid rg = ref_grid_of(scene, closest_hit != kRefWholeList);
     hipLaunchKernelGGL(render_ref_kernel<T>, dim3((unsigned)grid), dim3(block), 0, stream, cam, geom, mat, scene.kind,
-                       scene.n, ref_grid_of(scene, use_grid), part, key, flags, d_color, d_raw, d_count, d_counters);
+                       scene.n, rg, part, key, flags, d_color, d_raw, d_count, d_counters);
     return hipGetLastError();
 }
 
 } // namespace
 
 hipError_t launch_render_ref_f64(const CamDev<double>& cam, const SceneDev& scene, const Partition& part,
-                                 const RngKey& key, uint32_t flags, bool use_grid, uint32_t* d_color, double* d_raw,
+                                 const RngKey& key, uint32_t flags, int closest_hit, uint32_t* d_color, double* d_raw,
                                  int32_t* d_count, DeviceCounters* d_counters, hipStream_t stream) {
-    return launch_ref<double>(cam, scene.geom64, scene.mat64, scene, part, key, flags, use_grid, d_color, d_raw, d_count,
+    return launch_ref<double>(cam, scene.geom64, scene.mat64, scene, part, key, flags, closest_hit, d_color, d_raw, d_count,
                               d_counters, stream);
+}
+
+bool plan_render_f64_stream(const CamDev<double>& cam, const Partition& part, const SceneDev& scene, int device,
+                            F64StreamPlan* plan) {
+    const long long npix = (long long)part.n_rows * cam.W;
+    if (npix <= 0 || npix > 0x7fffffffLL || cam.spp <= 0) return false;
+    if (!ref_grid_of(scene, true).use) return false;
+    // compute units of the device and resident blocks per unit: asked once per device
+    struct DeviceFacts { int cus = 0, occ = 0; };
+    static DeviceFacts facts[64];
+    static std::mutex facts_mu;
+    int cus = 256, occ = 2;
+    {
+        std::lock_guard<std::mutex> lock(facts_mu);
+        DeviceFacts local;
+        DeviceFacts& f = (device >= 0 && device < 64) ? facts[device] : local;
+        if (f.cus == 0) {
+            int v = 0;
+            f.cus = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && v > 0) ? v : 256;
+            f.occ = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, render_f64_stream_kernel, 256, 0) == hipSuccess && v > 0) ? v : 2;
+        }
+        cus = f.cus;
+        occ = f.occ;
+    }
+    plan->block = 256;
+    plan->grid = cus * occ;
+    // a chunk holds at least 256 samples: one returning atomic per chunk on the queue's counter, which serves
+    // some 80 M of them per second
+    const uint32_t spp = (uint32_t)cam.spp;
+    plan->chunk_pixels = (256u + spp - 1u) / spp;
+    const long long chunks = (npix + plan->chunk_pixels - 1) / plan->chunk_pixels;
+    const long long blocks_needed = (chunks + 3) / 4; // a wave needs a chunk to have anything to do
+    if (blocks_needed < plan->grid) plan->grid = (int32_t)blocks_needed;
+    plan->ring_bytes = (size_t)plan->grid * 4u * kF64RingEntries * sizeof(RingEntry);
+    return true;
+}
+
+hipError_t launch_render_f64_stream(const CamDev<double>& cam, const SceneDev& scene, const Partition& part,
+                                    const RngKey& key, uint32_t flags, const F64StreamPlan& plan, uint32_t* d_color,
+                                    double* d_raw, int32_t* d_count, DeviceCounters* d_counters, void* rings,
+                                    uint32_t launch_number, hipStream_t stream) {
+    if (!rings || !d_counters || launch_number == 0u) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(render_f64_stream_kernel, dim3((unsigned)plan.grid), dim3(plan.block), 0, stream, cam, scene.geom64,
+                       scene.mat64, scene.kind, scene.n, ref_grid_of(scene, true), part, key, flags, d_color, d_raw, d_count,
+                       d_counters, (RingEntry*)rings, launch_number, plan.chunk_pixels);
+    return hipGetLastError();
 }
 
 hipError_t launch_render_ref_f32(const CamDev<float>& cam, const SceneDev& scene, const Partition& part,
                                  const RngKey& key, uint32_t flags, uint32_t* d_color, double* d_raw, int32_t* d_count,
                                  DeviceCounters* d_counters, hipStream_t stream) {
-    return launch_ref<float>(cam, scene.geom32, scene.mat32, scene, part, key, flags, false, d_color, d_raw, d_count,
+    return launch_ref<float>(cam, scene.geom32, scene.mat32, scene, part, key, flags, kRefWholeList, d_color, d_raw, d_count,
                              d_counters, stream);
 }
 

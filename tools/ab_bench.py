@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""A/B timing of f32 scan variants (and, via DRAY_HIP_LIB, of two builds) in ONE process on one GPU:
+"""A/B timing of f32 scan variants or f64 organisations (and, via DRAY_HIP_LIB, of two builds) in ONE process on one GPU:
 interleaved rounds, median and minimum trace-kernel time per arm.
 
     python tools/ab_bench.py --variants 0 1 2 --rounds 5 [--spp 100] [--width 1200]
@@ -24,6 +24,8 @@ def main():
     ap.add_argument("--ppp", type=int, nargs="+", default=[0], help="pixels per pool values to try")
     ap.add_argument("--scene", default="final", choices=["final", "three", "grid10k", "glass_metal"])
     ap.add_argument("--tag", default="")
+    ap.add_argument("--mode", default="f32", choices=["f32", "f64"],
+                    help="f64: the variants are the f64 render's organisations (0/3 by wave, 2 by pixel, 1 whole list)")
     args = ap.parse_args()
     import dray_amd as d
     from dray_amd import device as ddev
@@ -31,7 +33,7 @@ def main():
         args.scene, lambda seed: d.scene_three_spheres())(1)
     cam = (d.camera_three_spheres if args.scene == "three" else d.camera_final)(width=args.width, spp=args.spp,
                                                                                  depth=args.depth)
-    cam.mode = d.MODE_F32
+    cam.mode = d.MODE_F64 if args.mode == "f64" else d.MODE_F32
     scene = ddev.DeviceScene(spheres, 0)
     color, raw, count = ddev.alloc_buffers(cam, 0)
     arms = [(v, s) for v in args.variants for s in args.ppp]
