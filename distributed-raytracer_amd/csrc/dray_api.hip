@@ -29,7 +29,6 @@ struct dray_scene {
     size_t accum_capacity = 0;             // in u64 words
     void* d_rings = nullptr;               // the f64 stream kernel's rings of finished samples (one per resident wave)
     size_t rings_bytes = 0;
-    uint32_t ring_launches = 0;            // launches that have used the rings: entries are tagged with their launch
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     // The counters, the sums and the events are one set per scene, so a scene serves one call at a time: host
     // threads take `mu` for the length of a call, and a call enqueued on another stream than the one before it
@@ -174,6 +173,7 @@ void scene_free(dray_scene* s) {
     (void)hipFree(d.narrow_index); (void)hipFree(d.wide_index);
     (void)hipFree(d.grid_cells); (void)hipFree(d.grid_entry_geom); (void)hipFree(d.grid_entry_pos); (void)hipFree(d.grid_loose);
     (void)hipFree(d.box64); (void)hipFree(d.box_index);
+    (void)hipFree(d.entry_geom64); (void)hipFree(d.entry_index); (void)hipFree(d.always_geom64); (void)hipFree(d.always_index);
     (void)hipFree(s->d_counters); (void)hipFree(s->d_accum); (void)hipFree(s->d_rings);
     for (auto& e : s->ev)
         if (e) (void)hipEventDestroy(e);
@@ -492,6 +492,25 @@ int scene_create_impl(const dray_sphere* sp, size_t n, int32_t device, dray_scen
     d.grid.entry_pos = d.grid_entry_pos;
     d.grid.loose = d.grid_loose;
     d.grid_entries = grid.entry_pos.size();
+    { // the grid's lists once more with list positions and f64 geometry, for the f64 stream kernel
+        std::vector<double> eg(4 * grid.entry_pos.size());
+        std::vector<int32_t> ei(grid.entry_pos.size());
+        for (size_t e = 0; e < grid.entry_pos.size(); ++e) {
+            ei[e] = nidx[grid.entry_pos[e]];
+            for (int q = 0; q < 4; ++q) eg[4 * e + q] = g64[4 * (size_t)ei[e] + q];
+        }
+        std::vector<int32_t> ai(widx);
+        for (int32_t p : grid.loose) ai.push_back(nidx[p]);
+        std::vector<double> ag(4 * ai.size());
+        for (size_t k = 0; k < ai.size(); ++k)
+            for (int q = 0; q < 4; ++q) ag[4 * k + q] = g64[4 * (size_t)ai[k] + q];
+        d.n_always = (int32_t)ai.size();
+        if ((rc = upload(&d.entry_geom64, eg)) || (rc = upload(&d.entry_index, ei)) || (rc = upload(&d.always_geom64, ag)) ||
+            (rc = upload(&d.always_index, ai))) {
+            scene_free(s);
+            return rc;
+        }
+    }
     // The throughput kernel renders Transparent (material.rs:22-31) as the absorber it amounts to: the ray it hands
     // back meets the same sphere again at every depth left and the sample comes out black.  (Only the statistics
     // differ: that kernel counts one segment where the reference-order kernels walk through the depths left.)
@@ -711,22 +730,14 @@ struct RenderJob {
                 if (how == kRefGridAsStream && !plan_render_f64_stream(c, part, scene->dev, scene->device, &sp)) how = kRefGridByPixel;
                 if (how == kRefGridAsStream) {
                     if (sp.ring_bytes > scene->rings_bytes) {
-                        if (scene->d_rings) HIP_TRY(hipFree(scene->d_rings));
+                        if (scene->d_rings) HIP_TRY(hipFree(scene->d_rings)); // waits for the device: no earlier call still uses it
                         scene->d_rings = nullptr;
                         scene->rings_bytes = 0;
                         HIP_TRY(hipMalloc(&scene->d_rings, sp.ring_bytes));
-                        // tag 0: written by no launch.  On the launch's own stream: a clear queued anywhere else could
-                        // still be running when the kernel writes its first tags, and wipe them
-                        HIP_TRY(hipMemsetAsync(scene->d_rings, 0, sp.ring_bytes, stream));
                         scene->rings_bytes = sp.ring_bytes;
-                        scene->ring_launches = 0;
-                    }
-                    if (++scene->ring_launches == 0u) { // the launch number has wrapped: forget every old tag
-                        HIP_TRY(hipMemsetAsync(scene->d_rings, 0, scene->rings_bytes, stream));
-                        scene->ring_launches = 1u;
                     }
                     HIP_TRY(launch_render_f64_stream(c, scene->dev, part, key, opts.flags, sp, d_color, d_raw, d_count,
-                                                     d_counters, scene->d_rings, scene->ring_launches, stream));
+                                                     d_counters, scene->d_rings, stream));
                 } else {
                     HIP_TRY(launch_render_ref_f64(c, scene->dev, part, key, opts.flags, how, d_color, d_raw, d_count,
                                                   d_counters, stream));

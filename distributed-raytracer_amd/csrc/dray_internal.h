@@ -93,6 +93,12 @@ struct SceneDev {
     int32_t* grid_loose = nullptr;
     size_t grid_entries = 0;
     GridDev grid{};
+    // the same lists for the f64 stream kernel, with the f64 geometry beside them so that a test costs one load:
+    double* entry_geom64 = nullptr;   // per grid entry: cx, cy, cz, radius
+    int32_t* entry_index = nullptr;   // per grid entry: the sphere's position in the caller's list
+    double* always_geom64 = nullptr;  // the spheres every ray is tested against (wide, then loose): cx, cy, cz, radius
+    int32_t* always_index = nullptr;  // their positions in the caller's list
+    int32_t n_always = 0;
 };
 
 // A workgroup of the f32 kernel may hold 64 KiB of LDS: its static arrays (pixel sums, tags, draw requests) plus,
@@ -128,11 +134,11 @@ struct F64StreamPlan {
 // false: this frame or scene is not for the stream kernel (no grid over the scene, no samples)
 bool plan_render_f64_stream(const CamDev<double>& cam, const Partition& part, const SceneDev& scene, int device,
                             F64StreamPlan* plan);
-// `rings`: plan.ring_bytes of device memory, zero before its first use; `launch_number`: 1, 2, ... per use of that memory
+// `rings`: plan.ring_bytes of device memory (its contents do not matter)
 hipError_t launch_render_f64_stream(const CamDev<double>& cam, const SceneDev& scene, const Partition& part,
                                     const RngKey& key, uint32_t flags, const F64StreamPlan& plan, uint32_t* d_color,
                                     double* d_raw, int32_t* d_count, DeviceCounters* d_counters, void* rings,
-                                    uint32_t launch_number, hipStream_t stream);
+                                    hipStream_t stream);
 hipError_t launch_render_ref_f32(const CamDev<float>& cam, const SceneDev& scene, const Partition& part,
                                  const RngKey& key, uint32_t flags, uint32_t* d_color, double* d_raw, int32_t* d_count,
                                  DeviceCounters* d_counters, hipStream_t stream);

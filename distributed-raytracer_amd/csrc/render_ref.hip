@@ -96,6 +96,12 @@ struct RefGrid {
     const double* box64;
     const int32_t* box_index;
     int32_t n_boxes;
+    // the stream kernel's copies of the lists, with the f64 geometry beside the list positions (SceneDev)
+    const double* entry_geom64;
+    const int32_t* entry_index;
+    const double* always_geom64;
+    const int32_t* always_index;
+    int32_t n_always;
 };
 
 // BoundingBox::hit, bounding_box.rs:50-76, up to the choice of the root, for an upper bound of +infinity (a smaller
@@ -153,10 +159,8 @@ __device__ __forceinline__ bool boxes_hit(const RefGrid& rg, V3<T> ro, V3<T> rd,
 // of +infinity, or no root.  (With a smaller bound the reference accepts the same root or none: the far root is only
 // tried when the near one is not above tmin, or not below the bound -- and then the far one is not below it either.)
 template <typename T>
-__device__ __forceinline__ bool sphere_root(const T* __restrict__ geom, int32_t k, V3<T> ro, V3<T> rd, T& root) {
+__device__ __forceinline__ bool sphere_root_of(V3<T> center, T radius, V3<T> ro, V3<T> rd, T& root) {
     const T tmin = (T)0.001;
-    const V3<T> center = {geom[4 * k + 0], geom[4 * k + 1], geom[4 * k + 2]};
-    const T radius = geom[4 * k + 3];
     V3<T> oc = vsub(center, ro);
     T a = vlen2(rd);
     T h = vdot(rd, oc);
@@ -170,6 +174,10 @@ __device__ __forceinline__ bool sphere_root(const T* __restrict__ geom, int32_t 
         if (!(tmin < root)) return false;
     }
     return root < (T)INFINITY;
+}
+template <typename T>
+__device__ __forceinline__ bool sphere_root(const T* __restrict__ geom, int32_t k, V3<T> ro, V3<T> rd, T& root) {
+    return sphere_root_of<T>(V3<T>{geom[4 * k + 0], geom[4 * k + 1], geom[4 * k + 2]}, geom[4 * k + 3], ro, rd, root);
 }
 
 // sphere.rs:49-55 for the accepted root
@@ -520,9 +528,24 @@ __global__ __launch_bounds__(256) void render_ref_kernel(CamDev<T> cam, const T*
 // and the walked spheres).  A ray that is not finite, or a walk that outlasts a straight line, takes the scan of
 // the whole list, as there.
 
+// Pointer into the constant address space: a wave-uniform read through it is a scalar load.
+#define DRAY_CONSTANT __attribute__((address_space(4)))
+template <typename T>
+__device__ __forceinline__ const DRAY_CONSTANT T* as_constant(const T* p) {
+    return (const DRAY_CONSTANT T*)p;
+}
+
+// lane `k`'s value (k the same in every lane)
+__device__ __forceinline__ double readlane_f64(double v, int k) {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)u, k);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(u >> 32), k);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
 enum { kDraw64None = 0, kDraw64UnitVector = 1, kDraw64UnitDisk = 2 };
 #ifndef DRAY_F64_WALK_QUORUM
-#define DRAY_F64_WALK_QUORUM 16
+#define DRAY_F64_WALK_QUORUM 8
 #endif
 
 struct Drawn {
@@ -586,22 +609,37 @@ struct Walk64 {
     int32_t best;
 };
 
-__device__ __forceinline__ void test64(const double* __restrict__ geom, int32_t k, V3<double> ro, V3<double> rd,
-                                       Walk64& w) {
+// One sphere (centre, radius, position in the caller's list) against the walk's closest hit so far.
+__device__ __forceinline__ void test64(V3<double> center, double radius, int32_t k, V3<double> ro, V3<double> rd, Walk64& w) {
     double root;
-    if (sphere_root<double>(geom, k, ro, rd, root) && (root < w.closest || (root == w.closest && k < w.best))) {
+    if (sphere_root_of<double>(center, radius, ro, rd, root) && (root < w.closest || (root == w.closest && k < w.best))) {
         w.closest = root;
         w.best = k;
     }
 }
 
-// One finished sample in a wave's ring: the colour that joins the pixel's sum (camera.rs:223-225: 0 + sample), and
-// which sample of which launch wrote it.
+// Diagnostic builds only (tools/f64_clocks.py): with DRAY_F64_CLOCKS a wave adds up the shader clocks it spends in
+// each section of its main loop, and how often a few things happen.
+#ifdef DRAY_F64_CLOCKS
+__device__ unsigned long long dray_f64_clocks[32];
+#define F64_CLOCK(slot)                                              \
+    do {                                                             \
+        const unsigned long long now__ = __builtin_amdgcn_s_memtime(); \
+        clk[slot] += now__ - clk_t;                                  \
+        clk_t = now__;                                               \
+    } while (0)
+#define F64_COUNT(slot, v) (clk[slot] += (unsigned long long)(v))
+#else
+#define F64_CLOCK(slot)
+#define F64_COUNT(slot, v)
+#endif
+
+// One finished sample in a wave's ring: the colour that joins the pixel's sum (camera.rs:223-225: 0 + sample).
 struct RingEntry {
     double r, g, b;
-    unsigned long long tag; // launch number << 32 | the sample's number in the wave's stream + 1
+    double unused; // entries are 32 bytes apart
 };
-static_assert(sizeof(RingEntry) == 32, "a ring entry is two 16-byte stores");
+static_assert(sizeof(RingEntry) == 32, "ring entries are 32 bytes apart");
 constexpr uint32_t kFifoSlots = 16; // chunks a wave may have grabbed and not begun to retire
 
 #ifndef DRAY_F64_WAVES_PER_EU
@@ -613,7 +651,7 @@ void render_f64_stream_kernel(CamDev<double> cam, const double* __restrict__ geo
                               const uint32_t* __restrict__ kind, int32_t n, RefGrid rg, Partition part, RngKey key,
                               uint32_t flags, uint32_t* __restrict__ color, double* __restrict__ raw,
                               int32_t* __restrict__ count, DeviceCounters* counters, RingEntry* rings,
-                              uint32_t launch_number, uint32_t chunk_pixels) {
+                              uint32_t chunk_pixels) {
     __shared__ uint4 lds_req[4][64];           // coop_draw64: streams handed to server lanes, one set of slots per wave
     __shared__ uint32_t lds_fifo[4][kFifoSlots]; // first pixel of the chunks the wave has grabbed, oldest first
     const int lane = (int)(threadIdx.x & 63u), wv = (int)(threadIdx.x >> 6);
@@ -621,7 +659,6 @@ void render_f64_stream_kernel(CamDev<double> cam, const double* __restrict__ geo
     const uint32_t W = (uint32_t)cam.W, spp = (uint32_t)cam.spp, npix = (uint32_t)part.n_rows * W;
     const bool iterative = (flags & DRAY_FLAG_ITERATIVE_PRODUCT) != 0;
     RingEntry* ring = rings + (size_t)(blockIdx.x * 4u + (uint32_t)wv) * kF64RingEntries;
-    const unsigned long long tag_base = (unsigned long long)launch_number << 32;
     const int32_t max_steps = g.n[0] + g.n[1] + g.n[2] + 4;
     unsigned long long my_segments = 0;
 
@@ -658,11 +695,19 @@ void render_f64_stream_kernel(CamDev<double> cam, const double* __restrict__ geo
     unsigned long long n_samples = 0ull;
     bool exhausted = false;
 
+#ifdef DRAY_F64_CLOCKS
+    unsigned long long clk[32] = {};
+    unsigned long long clk_t = __builtin_amdgcn_s_memtime();
+#endif
     for (;;) {
+        F64_COUNT(16, 1);                              // turns
+        F64_COUNT(17, __popcll(__ballot(has)));        // lanes carrying a sample
         // ---- walk steps, while enough lanes are on their way --------------------------------------------------
         {
             const int quorum = exhausted ? 1 : DRAY_F64_WALK_QUORUM;
             do { // at least one step a turn: fewer lanes than a quorum may be all the wave has
+                F64_COUNT(18, 1);                              // walk steps
+                F64_COUNT(19, __popcll(__ballot(walking)));    // lanes walking at them
                 if (walking) {
                     if (wk.e == wk.e_end) { // this cell is done: stop, or step into the next one
                         const double tx = (double)wk.c[0] * wk.A[0] + wk.B[0], ty = (double)wk.c[1] * wk.A[1] + wk.B[1],
@@ -689,13 +734,15 @@ void render_f64_stream_kernel(CamDev<double> cam, const double* __restrict__ geo
                         wk.e_end = go ? cellrec.x + cellrec.y : cellrec.x;
                     }
                     if (wk.e != wk.e_end) {
-                        test64(geom, rg.narrow_index[g.entry_pos[wk.e]], ro, rd, wk);
+                        const double* eg = rg.entry_geom64 + 4 * (size_t)wk.e;
+                        test64(V3<double>{eg[0], eg[1], eg[2]}, eg[3], rg.entry_index[wk.e], ro, rd, wk);
                         ++wk.e;
                     }
                 }
             } while (__popcll(__ballot(walking)) >= quorum);
         }
 
+        F64_CLOCK(0);
         // ---- lanes whose walk is over: the hit (hittable_list.rs:60-74 / sphere.rs:49-55), or the sky -----------
         const bool ready = has && !walking && !camera;
         Hit<double> rec = {};
@@ -729,34 +776,55 @@ void render_f64_stream_kernel(CamDev<double> cam, const double* __restrict__ geo
             }
         }
 
+        F64_CLOCK(1);
+        F64_COUNT(20, __popcll(__ballot(ready)));      // lanes shading
         // ---- samples that end here: their colour goes to its place in the wave's ring ---------------------------
         if (ended) {
             if (iterative) {
                 c = vmul(att, c); // camera.rs:121,135,142
             } else {
-                while (sp > 0) { // camera.rs:274, innermost product first
-                    const uint32_t q = stack[--sp];
-                    c = vmul(V3<double>{mat[4 * q], mat[4 * q + 1], mat[4 * q + 2]}, c);
+                while (sp > 0) { // camera.rs:274, innermost product first; four albedos are fetched at a time
+                    const int32_t n4 = sp < 4 ? sp : 4;
+                    uint32_t q[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) q[u] = stack[sp - 1 - (u < n4 ? u : 0)];
+                    V3<double> al[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) al[u] = {mat[4 * q[u]], mat[4 * q[u] + 1], mat[4 * q[u] + 2]};
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (u < n4) c = vmul(al[u], c);
+                    sp -= n4;
                 }
             }
             RingEntry* e = ring + (item & (kF64RingEntries - 1u));
             e->r = 0. + c.x; // camera.rs:223-225: pixel_color = (0, 0, 0) + sample
             e->g = 0. + c.y;
             e->b = 0. + c.z;
-            e->tag = tag_base | (unsigned long long)(item + 1u);
             dead = false;
             has = false;
         }
 
+        F64_CLOCK(2);
         // ---- retire: the ring's finished samples, in the order of the stream, join their pixels (colors.rs:38-43) ----
-        if (retired != issued) {
-            const uint32_t at = retired + (uint32_t)lane;
-            const RingEntry* e = ring + (at & (kF64RingEntries - 1u));
-            // (this wave wrote the entry, through the same cache: an earlier store is seen by this load)
-            const double er = e->r, eg = e->g, eb = e->b;
-            const bool ok = at - retired < issued - retired && e->tag == (tag_base | (unsigned long long)(at + 1u));
-            const unsigned long long okm = __ballot(ok);
-            const int n_ok = ~okm == 0ull ? 64 : __builtin_ctzll(~okm); // finished samples at the head of the stream
+        // Every sample of the stream below `issued` is either in a lane or finished, so the samples before the oldest
+        // one in a lane are all in the ring.  The wave retires them 64 at a time (a look at the ring is a trip to
+        // memory), and whatever is finished once the queue has run out.
+        for (;;) {
+            const uint32_t waiting = issued - retired;
+            int n_ok = 0;
+            if (waiting >= 64u && __ballot(has && item - retired < 64u) == 0ull) {
+                n_ok = 64;
+            } else if (exhausted && waiting != 0u) {
+                uint32_t oldest = has ? item - retired : waiting; // of the samples still in lanes
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) oldest = min(oldest, (uint32_t)__shfl_xor((int)oldest, off, 64));
+                n_ok = (int)min(oldest, 64u);
+            }
+            if (n_ok == 0) break;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // the lanes' stores to the ring have completed
+            const RingEntry* e = ring + ((retired + (uint32_t)lane) & (kF64RingEntries - 1u));
+            const double er = e->r, eg = e->g, eb = e->b; // (lanes past n_ok read entries nobody uses)
             for (int k = 0; k < n_ok; ++k) {
                 if (ret_s == 0u) { // a pixel begins
                     if (ret_dp == ret_np) { // ... and with it a chunk
@@ -770,9 +838,9 @@ void render_f64_stream_kernel(CamDev<double> cam, const double* __restrict__ geo
                     acc[0] = acc[1] = acc[2] = 0.;
                     if (raw) { acc[0] = raw[3 * ret_out + 0]; acc[1] = raw[3 * ret_out + 1]; acc[2] = raw[3 * ret_out + 2]; }
                 }
-                acc[0] += __shfl(er, k, 64); // colors.rs:38
-                acc[1] += __shfl(eg, k, 64);
-                acc[2] += __shfl(eb, k, 64);
+                acc[0] += readlane_f64(er, k); // colors.rs:38
+                acc[1] += readlane_f64(eg, k);
+                acc[2] += readlane_f64(eb, k);
                 if (++ret_s == spp) { // the pixel is complete
                     if (lane == 0) {
                         const int32_t cnt = (count ? count[ret_out] : 0) + (int32_t)spp; // colors.rs:39
@@ -789,6 +857,7 @@ void render_f64_stream_kernel(CamDev<double> cam, const double* __restrict__ geo
             n_samples += (unsigned long long)n_ok;
         }
 
+        F64_CLOCK(3);
         // ---- refill: free lanes take the next samples of the stream (camera.rs:217-224) ------------------------
         {
             bool need = !has;
@@ -835,6 +904,7 @@ void render_f64_stream_kernel(CamDev<double> cam, const double* __restrict__ geo
         }
         if (__ballot(has) == 0ull && retired == issued) break; // nothing in flight, nothing left to take
 
+        F64_CLOCK(4);
         // ---- the first uniforms of the next step, and the rejection samplers, by the whole wave -----------------
         const bool draws = scatters || camera;
         const Stream st = {key.k0, key.k1, pw, key.sample_offset + smp, camera ? 0u : (uint32_t)(cam.max_depth - depth + 1)};
@@ -843,7 +913,9 @@ void render_f64_stream_kernel(CamDev<double> cam, const double* __restrict__ geo
         const uint32_t draw = (scatters && (mk == DRAY_MAT_LAMBERTIAN || mk == DRAY_MAT_METAL)) ? (uint32_t)kDraw64UnitVector
                               : (camera && cam.defocus != 0)                                      ? (uint32_t)kDraw64UnitDisk
                                                                                                   : (uint32_t)kDraw64None;
+        F64_CLOCK(5);
         const Drawn got = coop_draw64(st, w, draw, lds_req[wv], lane);
+        F64_CLOCK(6);
 
         // ---- scatter: material.rs -------------------------------------------------------------------------
         bool fresh = false;
@@ -877,6 +949,7 @@ void render_f64_stream_kernel(CamDev<double> cam, const double* __restrict__ geo
             }
         }
 
+        F64_CLOCK(7);
         // ---- camera ray of a new sample: camera.rs:238-262 --------------------------------------------------
         if (camera) {
             double px = 0., py = 0.;
@@ -890,6 +963,7 @@ void render_f64_stream_kernel(CamDev<double> cam, const double* __restrict__ geo
             fresh = depth > 0;
         }
 
+        F64_CLOCK(8);
         // ---- a new ray: the spheres every ray meets, then its first cell ------------------------------------------
         if (fresh) {
             my_segments++;
@@ -906,8 +980,22 @@ void render_f64_stream_kernel(CamDev<double> cam, const double* __restrict__ geo
             if (!finite) {
                 fallback = true;
             } else {
-                for (int32_t q = 0; q < rg.n_wide; ++q) test64(geom, rg.wide_index[q], ro, rd, wk);
-                for (int32_t q = 0; q < g.n_loose; ++q) test64(geom, rg.narrow_index[g.loose[q]], ro, rd, wk);
+                {
+                    const DRAY_CONSTANT double* ag = as_constant(rg.always_geom64);
+                    const DRAY_CONSTANT int32_t* ai = as_constant(rg.always_index);
+                    // the wide and the loose spheres (scalar loads), four at a time so that their chains of f64
+                    // operations run side by side
+                    const int32_t n_always = rg.n_always;
+                    int32_t q = 0;
+                    for (; q + 4 <= n_always; q += 4) {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            test64(V3<double>{ag[4 * (q + u)], ag[4 * (q + u) + 1], ag[4 * (q + u) + 2]}, ag[4 * (q + u) + 3],
+                                   ai[q + u], ro, rd, wk);
+                    }
+                    for (; q < n_always; ++q)
+                        test64(V3<double>{ag[4 * q], ag[4 * q + 1], ag[4 * q + 2]}, ag[4 * q + 3], ai[q], ro, rd, wk);
+                }
                 if (g.n[0] > 0) {
                     double t_in = 0., t_out = INFINITY, bmax = 0.;
                     bool inside_slabs = true;
@@ -942,7 +1030,13 @@ void render_f64_stream_kernel(CamDev<double> cam, const double* __restrict__ geo
                 }
             }
         }
+        F64_CLOCK(9);
     }
+#ifdef DRAY_F64_CLOCKS
+    if (lane == 0)
+        for (int q = 0; q < 32; ++q)
+            if (clk[q]) atomicAdd(&dray_f64_clocks[q], clk[q]);
+#endif
 
     // one atomic per wave
     for (int off = 32; off > 0; off >>= 1) my_segments += __shfl_down(my_segments, off, 64);
@@ -1037,6 +1131,11 @@ RefGrid ref_grid_of(const SceneDev& scene, bool use) {
     rg.box64 = scene.box64;
     rg.box_index = scene.box_index;
     rg.n_boxes = scene.n_boxes;
+    rg.entry_geom64 = scene.entry_geom64;
+    rg.entry_index = scene.entry_index;
+    rg.always_geom64 = scene.always_geom64;
+    rg.always_index = scene.always_index;
+    rg.n_always = scene.n_always;
     return rg;
 }
 
@@ -1102,13 +1201,22 @@ bool plan_render_f64_stream(const CamDev<double>& cam, const Partition& part, co
 hipError_t launch_render_f64_stream(const CamDev<double>& cam, const SceneDev& scene, const Partition& part,
                                     const RngKey& key, uint32_t flags, const F64StreamPlan& plan, uint32_t* d_color,
                                     double* d_raw, int32_t* d_count, DeviceCounters* d_counters, void* rings,
-                                    uint32_t launch_number, hipStream_t stream) {
-    if (!rings || !d_counters || launch_number == 0u) return hipErrorInvalidValue;
+                                    hipStream_t stream) {
+    if (!rings || !d_counters) return hipErrorInvalidValue;
     hipLaunchKernelGGL(render_f64_stream_kernel, dim3((unsigned)plan.grid), dim3(plan.block), 0, stream, cam, scene.geom64,
                        scene.mat64, scene.kind, scene.n, ref_grid_of(scene, true), part, key, flags, d_color, d_raw, d_count,
-                       d_counters, (RingEntry*)rings, launch_number, plan.chunk_pixels);
+                       d_counters, (RingEntry*)rings, plan.chunk_pixels);
     return hipGetLastError();
 }
+
+#ifdef DRAY_F64_CLOCKS
+// Diagnostic builds only: reads and clears the stream kernel's section clocks.
+extern "C" int dray_debug_f64_clocks(unsigned long long* out) {
+    unsigned long long zero[32] = {};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(dray_f64_clocks), sizeof zero) != hipSuccess) return -1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(dray_f64_clocks), zero, sizeof zero) == hipSuccess ? 0 : -1;
+}
+#endif
 
 hipError_t launch_render_ref_f32(const CamDev<float>& cam, const SceneDev& scene, const Partition& part,
                                  const RngKey& key, uint32_t flags, uint32_t* d_color, double* d_raw, int32_t* d_count,
