@@ -646,6 +646,7 @@ constexpr uint32_t kFifoSlots = 16; // chunks a wave may have grabbed and not be
 #define DRAY_F64_WAVES_PER_EU 3
 #endif
 
+template <bool ITERATIVE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DRAY_F64_WAVES_PER_EU, DRAY_F64_WAVES_PER_EU)))
 void render_f64_stream_kernel(CamDev<double> cam, const double* __restrict__ geom, const double* __restrict__ mat,
                               const uint32_t* __restrict__ kind, int32_t n, RefGrid rg, Partition part, RngKey key,
@@ -654,10 +655,11 @@ void render_f64_stream_kernel(CamDev<double> cam, const double* __restrict__ geo
                               uint32_t chunk_pixels) {
     __shared__ uint4 lds_req[4][64];           // coop_draw64: streams handed to server lanes, one set of slots per wave
     __shared__ uint32_t lds_fifo[4][kFifoSlots]; // first pixel of the chunks the wave has grabbed, oldest first
+    __shared__ double lds_stage[4][64][3];       // the colours of the samples being retired
     const int lane = (int)(threadIdx.x & 63u), wv = (int)(threadIdx.x >> 6);
     const GridDev& g = rg.grid;
     const uint32_t W = (uint32_t)cam.W, spp = (uint32_t)cam.spp, npix = (uint32_t)part.n_rows * W;
-    const bool iterative = (flags & DRAY_FLAG_ITERATIVE_PRODUCT) != 0;
+    constexpr bool iterative = ITERATIVE; // how a sample's attenuations are multiplied (camera.rs:130 or :274)
     RingEntry* ring = rings + (size_t)(blockIdx.x * 4u + (uint32_t)wv) * kF64RingEntries;
     const int32_t max_steps = g.n[0] + g.n[1] + g.n[2] + 4;
     unsigned long long my_segments = 0;
@@ -671,7 +673,7 @@ void render_f64_stream_kernel(CamDev<double> cam, const double* __restrict__ geo
     };
 
     // per-lane state: one sample's path
-    uint32_t stack[kExactMaxDepth]; // spheres whose albedo multiplies the sample, outermost first
+    uint32_t stack[ITERATIVE ? 1 : kExactMaxDepth]; // spheres whose albedo multiplies the sample, outermost first
     V3<double> ro = {0., 0., 0.}, rd = {0., 0., 1.};
     V3<double> att = {1., 1., 1.}; // camera.rs:26 (iterative form)
     uint32_t pw = 0u, smp = 0u, item = 0u; // the sample: Philox pixel word, sample number, number in the wave's stream
@@ -691,7 +693,7 @@ void render_f64_stream_kernel(CamDev<double> cam, const double* __restrict__ geo
     uint32_t iss_p0 = 0u, iss_q = 0u, iss_n = 0u;     // the chunk being handed out: first pixel, next sample, samples
     uint32_t ret_p0 = 0u, ret_dp = 0u, ret_np = 0u, ret_s = 0u; // the chunk being retired: first pixel, pixel, pixels; sample
     size_t ret_out = 0;
-    double acc[3] = {0., 0., 0.};             // running sum of the pixel being retired
+    double acc = 0.;                          // running sum of the pixel being retired: lane 0 red, 1 green, 2 blue
     unsigned long long n_samples = 0ull;
     bool exhausted = false;
 
@@ -743,6 +745,66 @@ void render_f64_stream_kernel(CamDev<double> cam, const double* __restrict__ geo
         }
 
         F64_CLOCK(0);
+        // ---- retire: the ring's finished samples, in the order of the stream, join their pixels (colors.rs:38-43) ----
+        // Every sample of the stream below `issued` is either in a lane or finished, so the samples before the oldest
+        // one in a lane are all in the ring.  The wave retires them 64 at a time (a look at the ring is a trip to
+        // memory), and whatever is finished once the queue has run out.
+        for (;;) {
+            const uint32_t waiting = issued - retired;
+            int n_ok = 0;
+            if (waiting >= 64u && __ballot(has && item - retired < 64u) == 0ull) {
+                n_ok = 64;
+            } else if (exhausted && waiting != 0u) {
+                uint32_t oldest = has ? item - retired : waiting; // of the samples still in lanes
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) oldest = min(oldest, (uint32_t)__shfl_xor((int)oldest, off, 64));
+                n_ok = (int)min(oldest, 64u);
+            }
+            if (n_ok == 0) break;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // the lanes' stores to the ring have completed
+            const RingEntry* e = ring + ((retired + (uint32_t)lane) & (kF64RingEntries - 1u));
+            // (lanes past n_ok read entries nobody uses.)  The colours go through LDS to lanes 0, 1, 2, which add up
+            // one channel each, sample after sample: one load and one addition per sample
+            lds_stage[wv][lane][0] = e->r;
+            lds_stage[wv][lane][1] = e->g;
+            lds_stage[wv][lane][2] = e->b;
+            const int ch = lane < 3 ? lane : 2;
+            int k = 0;
+            while (k < n_ok) {
+                if (ret_s == 0u) { // a pixel begins
+                    if (ret_dp == ret_np) { // ... and with it a chunk
+                        ret_p0 = lds_fifo[wv][begun & (kFifoSlots - 1u)];
+                        ret_np = min(chunk_pixels, npix - ret_p0);
+                        ret_dp = 0u;
+                        begun++;
+                    }
+                    uint32_t word;
+                    place_of(ret_p0 + ret_dp, ret_out, word);
+                    acc = raw ? raw[3 * ret_out + (size_t)ch] : 0.;
+                }
+                const int take = min(n_ok - k, (int)(spp - ret_s));
+#pragma unroll 8
+                for (int t = 0; t < take; ++t) acc += lds_stage[wv][k + t][ch]; // colors.rs:38
+                k += take;
+                ret_s += (uint32_t)take;
+                if (ret_s == spp) { // the pixel is complete
+                    const double a0 = readlane_f64(acc, 0), a1 = readlane_f64(acc, 1), a2 = readlane_f64(acc, 2);
+                    if (lane == 0) {
+                        const int32_t cnt = (count ? count[ret_out] : 0) + (int32_t)spp; // colors.rs:39
+                        const double denom = cnt != 0 ? (double)cnt : 1.;                 // colors.rs:40
+                        color[ret_out] = pack_argb(a0 / denom, a1 / denom, a2 / denom);
+                        if (raw) { raw[3 * ret_out + 0] = a0; raw[3 * ret_out + 1] = a1; raw[3 * ret_out + 2] = a2; }
+                        if (count) count[ret_out] = cnt;
+                    }
+                    ret_s = 0u;
+                    ret_dp++;
+                }
+            }
+            retired += (uint32_t)n_ok;
+            n_samples += (unsigned long long)n_ok;
+        }
+
+        F64_CLOCK(3);
         // ---- lanes whose walk is over: the hit (hittable_list.rs:60-74 / sphere.rs:49-55), or the sky -----------
         const bool ready = has && !walking && !camera;
         Hit<double> rec = {};
@@ -780,7 +842,7 @@ void render_f64_stream_kernel(CamDev<double> cam, const double* __restrict__ geo
         F64_COUNT(20, __popcll(__ballot(ready)));      // lanes shading
         // ---- samples that end here: their colour goes to its place in the wave's ring ---------------------------
         if (ended) {
-            if (iterative) {
+            if constexpr (iterative) {
                 c = vmul(att, c); // camera.rs:121,135,142
             } else {
                 while (sp > 0) { // camera.rs:274, innermost product first; four albedos are fetched at a time
@@ -806,58 +868,6 @@ void render_f64_stream_kernel(CamDev<double> cam, const double* __restrict__ geo
         }
 
         F64_CLOCK(2);
-        // ---- retire: the ring's finished samples, in the order of the stream, join their pixels (colors.rs:38-43) ----
-        // Every sample of the stream below `issued` is either in a lane or finished, so the samples before the oldest
-        // one in a lane are all in the ring.  The wave retires them 64 at a time (a look at the ring is a trip to
-        // memory), and whatever is finished once the queue has run out.
-        for (;;) {
-            const uint32_t waiting = issued - retired;
-            int n_ok = 0;
-            if (waiting >= 64u && __ballot(has && item - retired < 64u) == 0ull) {
-                n_ok = 64;
-            } else if (exhausted && waiting != 0u) {
-                uint32_t oldest = has ? item - retired : waiting; // of the samples still in lanes
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) oldest = min(oldest, (uint32_t)__shfl_xor((int)oldest, off, 64));
-                n_ok = (int)min(oldest, 64u);
-            }
-            if (n_ok == 0) break;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // the lanes' stores to the ring have completed
-            const RingEntry* e = ring + ((retired + (uint32_t)lane) & (kF64RingEntries - 1u));
-            const double er = e->r, eg = e->g, eb = e->b; // (lanes past n_ok read entries nobody uses)
-            for (int k = 0; k < n_ok; ++k) {
-                if (ret_s == 0u) { // a pixel begins
-                    if (ret_dp == ret_np) { // ... and with it a chunk
-                        ret_p0 = lds_fifo[wv][begun & (kFifoSlots - 1u)];
-                        ret_np = min(chunk_pixels, npix - ret_p0);
-                        ret_dp = 0u;
-                        begun++;
-                    }
-                    uint32_t word;
-                    place_of(ret_p0 + ret_dp, ret_out, word);
-                    acc[0] = acc[1] = acc[2] = 0.;
-                    if (raw) { acc[0] = raw[3 * ret_out + 0]; acc[1] = raw[3 * ret_out + 1]; acc[2] = raw[3 * ret_out + 2]; }
-                }
-                acc[0] += readlane_f64(er, k); // colors.rs:38
-                acc[1] += readlane_f64(eg, k);
-                acc[2] += readlane_f64(eb, k);
-                if (++ret_s == spp) { // the pixel is complete
-                    if (lane == 0) {
-                        const int32_t cnt = (count ? count[ret_out] : 0) + (int32_t)spp; // colors.rs:39
-                        const double denom = cnt != 0 ? (double)cnt : 1.;                 // colors.rs:40
-                        color[ret_out] = pack_argb(acc[0] / denom, acc[1] / denom, acc[2] / denom);
-                        if (raw) { raw[3 * ret_out + 0] = acc[0]; raw[3 * ret_out + 1] = acc[1]; raw[3 * ret_out + 2] = acc[2]; }
-                        if (count) count[ret_out] = cnt;
-                    }
-                    ret_s = 0u;
-                    ret_dp++;
-                }
-            }
-            retired += (uint32_t)n_ok;
-            n_samples += (unsigned long long)n_ok;
-        }
-
-        F64_CLOCK(3);
         // ---- refill: free lanes take the next samples of the stream (camera.rs:217-224) ------------------------
         {
             bool need = !has;
@@ -933,7 +943,7 @@ void render_f64_stream_kernel(CamDev<double> cam, const double* __restrict__ geo
                 [&]() { return u01<double>(w[0]); }, so, sd);
             if (scattered) {
                 const bool white = mk == DRAY_MAT_DIELECTRIC || mk == DRAY_MAT_TRANSPARENT; // attenuation (1, 1, 1)
-                if (iterative) {
+                if constexpr (iterative) {
                     V3<double> al = white ? V3<double>{1., 1., 1.}
                                           : V3<double>{mat[4 * rec.index], mat[4 * rec.index + 1], mat[4 * rec.index + 2]};
                     att = vmul(att, al); // camera.rs:130
@@ -1180,7 +1190,7 @@ bool plan_render_f64_stream(const CamDev<double>& cam, const Partition& part, co
         if (f.cus == 0) {
             int v = 0;
             f.cus = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && v > 0) ? v : 256;
-            f.occ = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, render_f64_stream_kernel, 256, 0) == hipSuccess && v > 0) ? v : 2;
+            f.occ = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, render_f64_stream_kernel<false>, 256, 0) == hipSuccess && v > 0) ? v : 2;
         }
         cus = f.cus;
         occ = f.occ;
@@ -1203,9 +1213,13 @@ hipError_t launch_render_f64_stream(const CamDev<double>& cam, const SceneDev& s
                                     double* d_raw, int32_t* d_count, DeviceCounters* d_counters, void* rings,
                                     hipStream_t stream) {
     if (!rings || !d_counters) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(render_f64_stream_kernel, dim3((unsigned)plan.grid), dim3(plan.block), 0, stream, cam, scene.geom64,
-                       scene.mat64, scene.kind, scene.n, ref_grid_of(scene, true), part, key, flags, d_color, d_raw, d_count,
-                       d_counters, (RingEntry*)rings, plan.chunk_pixels);
+    auto launch = [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, dim3((unsigned)plan.grid), dim3(plan.block), 0, stream, cam, scene.geom64, scene.mat64,
+                           scene.kind, scene.n, ref_grid_of(scene, true), part, key, flags, d_color, d_raw, d_count, d_counters,
+                           (RingEntry*)rings, plan.chunk_pixels);
+    };
+    if (flags & DRAY_FLAG_ITERATIVE_PRODUCT) launch(render_f64_stream_kernel<true>);
+    else launch(render_f64_stream_kernel<false>);
     return hipGetLastError();
 }
 
