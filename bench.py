@@ -246,7 +246,7 @@ def main():
         scan = {0: "grid" if n_spheres - 1 >= 40 else "hybrid", 1: "scalar", 2: "hybrid", 3: "grid"}[args.variant]
         scan_id = {"scalar": 1, "hybrid": 2, "grid": 3}[scan]
         kernel = "render_f32_kernel<%d>" % scan_id if args.mode == "f32" else (
-            "render_ref_kernel<double>" if args.mode == "f64" else "render_ref_kernel<float>")
+            "render_f64_stream_kernel" if args.mode == "f64" else "render_ref_kernel<float>")
         flops_per_launch = FLOP_PER_TEST * n_spheres * (segs / max(args.steps, 1))
         ref_equiv = flops_per_launch / k_s if k_s > 0 else 0.0
         # counters apply to the configuration they were taken on: one GPU, this config at full size, default options
@@ -321,14 +321,15 @@ def main():
                 "image_equals_default_scan": bool((cb == c32).all().item() and (rb == r32).all().item())}
             del cb, rb, nb
         if extra:
-            # the same frame at the reference's precision (vec3.rs:8-10): the f64 reference-order kernel, one launch
+            # the same frame at the reference's precision (vec3.rs:8-10): the f64 kernel (reference operation order, the
+            # frame run as a stream of samples), one launch
             cam64 = make_cam(width=width, spp=spp, depth=depth)
             cam64.lookfrom, cam64.focus_dist, cam64.seed, cam64.mode = cam.lookfrom, cam.focus_dist, args.seed, d.MODE_F64
             c64, r64, n64 = ddev.alloc_buffers(cam64, local_rank)
             st64 = ddev.render_device(cam64, scene, c64, r64, n64)
             k64 = st64.kernel_ms / 1e3
-            cnt64, cur64, cf64 = committed_counters(args.config, "render_ref_kernel<double>") if applies else (None, False, None)
-            leg = executed_roofline(cnt64, cur64, cf64, "render_ref_kernel<double>", k64, PEAK_FP64_VALU, f64=True)
+            cnt64, cur64, cf64 = committed_counters(args.config, "render_f64_stream_kernel") if applies else (None, False, None)
+            leg = executed_roofline(cnt64, cur64, cf64, "render_f64_stream_kernel<false>", k64, PEAK_FP64_VALU, f64=True)
             leg.update({"dtype": "f64", "mrays_s": st64.segments / k64 / 1e6 if k64 > 0 else 0.0, "segments": int(st64.segments),
                         "launches": 1})
             shifts = torch.tensor([16, 8, 0], device=c64.device)

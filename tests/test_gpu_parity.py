@@ -655,6 +655,9 @@ def test_f64_kernel_matches_oracle_on_random_scenes(dray, gpu, oracle):
         assert (raw == oraw).all() and (col == ocol).all() and (cnt == ocnt).all(), (k, what)
         lcol, lraw, _, lst = render_gpu(dray, gpu, sp, cam, variant=dray.SCAN_SCALAR)   # and through the scan of the whole list
         assert lst.segments == ost.segments and (lraw == oraw).all() and (lcol == ocol).all(), (k, what)
+        if k % 3 == 0:   # the grid walk inside the one-thread-per-pixel loop (the default is the stream of samples)
+            pcol, praw, _, pst = render_gpu(dray, gpu, sp, cam, variant=dray.SCAN_HYBRID)
+            assert pst.segments == ost.segments and (praw == oraw).all() and (pcol == ocol).all(), (k, what)
         cam.mode, cam.flags = dray.MODE_F32, 0
         col32, _, _, st32 = render_gpu(dray, gpu, sp, cam)
         ok = lsb_diff(col32, ocol).max(axis=-1) <= 1
@@ -883,7 +886,7 @@ def test_bounding_box_as_a_hittable(dray, gpu, oracle):
     for iterative in (0, 1):
         cam.mode, cam.flags = dray.MODE_F64, dray.FLAG_ITERATIVE_PRODUCT if iterative else 0
         ocol, oraw, ocnt, ost = oracle.render(ocam_from(oracle, cam), spheres, seed=14, iterative=iterative, threads=8)
-        for variant in (dray.SCAN_AUTO, dray.SCAN_SCALAR):
+        for variant in (dray.SCAN_AUTO, dray.SCAN_HYBRID, dray.SCAN_SCALAR):   # f64: stream of samples, per pixel, whole list
             col, raw, cnt, st = render_gpu(dray, gpu, spheres, cam, variant=variant)
             assert st.segments == ost.segments and (raw == oraw).all() and (col == ocol).all(), (iterative, variant)
         if not iterative:

@@ -20,6 +20,8 @@ def short_name(name):
     m = re.search(r"render_f32_kernel<(?:\(int\))?(\d), (?:\(bool\))?(?:false|0)>", name)   # the kernels without boxes
     if m:
         return "render_f32_kernel<%s>" % m.group(1)
+    if "render_f64_stream_kernel" in name:
+        return "render_f64_stream_kernel"
     if "render_ref_kernel<double>" in name:
         return "render_ref_kernel<double>"
     if "render_ref_kernel<float>" in name:
@@ -57,8 +59,8 @@ def merge(pass_dir, config, out_path):
             kernels[timed]["kernel_ms_under_counters"] = bench["roofline"]["kernel_ms"]
         if "roofline_bruteforce" in bench and "render_f32_kernel<2>" in kernels and timed != "render_f32_kernel<2>":
             kernels["render_f32_kernel<2>"]["kernel_ms_under_counters"] = bench["roofline_bruteforce"]["kernel_ms"]
-        if "f64_leg" in bench and "render_ref_kernel<double>" in kernels:
-            kernels["render_ref_kernel<double>"]["kernel_ms_under_counters"] = bench["f64_leg"]["kernel_ms"]
+        if "f64_leg" in bench and "render_f64_stream_kernel" in kernels:
+            kernels["render_f64_stream_kernel"]["kernel_ms_under_counters"] = bench["f64_leg"]["kernel_ms"]
     doc = {"config": int(config), "source_hash": source_hash(),
            "command": "bench.py --config %s --steps 1 --warmup 0 --no-cpu-baseline, one rocprofv3 --pmc pass per counter group; "
                       "values are per launch (each kernel's first dispatch of the pass)" % config,

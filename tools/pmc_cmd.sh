@@ -12,7 +12,7 @@ import csv, sys, json, glob, re
 vals, disp = {}, {}
 for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        k = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("dray::(anonymous namespace)::", "")
+        k = re.sub(r"\(.*", "", r["Kernel_Name"].replace("(anonymous namespace)::", ""))
         vals.setdefault(k, {})
         vals[k][r["Counter_Name"]] = vals[k].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
         disp.setdefault(k, set()).add(r["Dispatch_Id"])
