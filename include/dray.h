@@ -125,7 +125,12 @@ enum {
     DRAY_FLAG_NO_REFILL = 4u
 };
 
-/* Sphere-scan formulations of the f32 kernel; all give identical images. */
+/* Sphere-scan formulations of the f32 kernel; all give identical images.
+ * DRAY_MODE_F64 reads the same field as the way its kernel is organised, again with identical results (bit for bit):
+ * DRAY_SCAN_SCALAR = one thread per pixel, every sphere of the list tested per ray as hittable_list.rs:65-70 does;
+ * DRAY_SCAN_HYBRID = one thread per pixel, closest hit through the grid walk; DRAY_SCAN_AUTO / DRAY_SCAN_GRID = the
+ * grid walk with the frame run as a stream of samples over persistent waves, a pixel's samples still added in order
+ * (the fast one; it keeps a ring of finished samples per wave, some 200 MB per scene handle, allocated on first use). */
 enum {
     DRAY_SCAN_AUTO = 0,   /* grid for scenes of 40 spheres or more, else hybrid */
     DRAY_SCAN_SCALAR = 1, /* exact test on every sphere, geometry through scalar loads */
