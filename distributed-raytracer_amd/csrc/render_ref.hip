@@ -133,25 +133,38 @@ __device__ __forceinline__ bool box_root(const double* __restrict__ box, V3<T> r
 
 // The boxes of the list against the closest sphere hit so far: smallest root, on equal roots the earlier entry.
 // A box hit sets t and p (bounding_box.rs:63-64); its material reads neither normal nor face.
+struct BoxList {
+    const double* box64;
+    const int32_t* box_index;
+    int32_t n_boxes;
+};
 template <typename T>
-__device__ __forceinline__ bool boxes_hit(const RefGrid& rg, V3<T> ro, V3<T> rd, T closest, int32_t best, Hit<T>& rec) {
+__device__ __forceinline__ bool boxes_closest(const BoxList bl, V3<T> ro, V3<T> rd, T& closest, int32_t& best) {
     bool any = false;
-    for (int32_t q = 0; q < rg.n_boxes; ++q) {
-        const int32_t k = rg.box_index[q];
+    for (int32_t q = 0; q < bl.n_boxes; ++q) {
+        const int32_t k = bl.box_index[q];
         T root;
-        if (box_root<T>(rg.box64 + 6 * q, ro, rd, root) && (root < closest || (root == closest && k < best))) {
+        if (box_root<T>(bl.box64 + 6 * q, ro, rd, root) && (root < closest || (root == closest && k < best))) {
             closest = root;
             best = k;
             any = true;
         }
     }
-    if (any) {
-        rec.t = closest;
-        rec.p = vadd(ro, vscale(rd, closest)); // ray.rs:17-19
-        rec.normal = {(T)0., (T)0., (T)0.};
-        rec.front_face = false;
-        rec.index = best;
-    }
+    return any;
+}
+// The record of a box hit: t and p are set (bounding_box.rs:63-64); its material reads neither normal nor face.
+template <typename T>
+__device__ __forceinline__ void box_record(V3<T> ro, V3<T> rd, T closest, int32_t best, Hit<T>& rec) {
+    rec.t = closest;
+    rec.p = vadd(ro, vscale(rd, closest)); // ray.rs:17-19
+    rec.normal = {(T)0., (T)0., (T)0.};
+    rec.front_face = false;
+    rec.index = best;
+}
+template <typename T>
+__device__ __forceinline__ bool boxes_hit(const BoxList bl, V3<T> ro, V3<T> rd, T closest, int32_t best, Hit<T>& rec) {
+    const bool any = boxes_closest<T>(bl, ro, rd, closest, best);
+    if (any) box_record<T>(ro, rd, closest, best, rec);
     return any;
 }
 
@@ -206,7 +219,7 @@ __device__ __forceinline__ bool list_hit_linear(const T* __restrict__ geom, int3
             best = k;
         }
     }
-    if (boxes_hit<T>(rg, ro, rd, closest, best, rec)) return true;
+    if (boxes_hit<T>(BoxList{rg.box64, rg.box_index, rg.n_boxes}, ro, rd, closest, best, rec)) return true;
     if (best == 0x7fffffff) return false;
     fill_hit(geom, best, ro, rd, closest, rec);
     return true;
@@ -283,7 +296,7 @@ __device__ __forceinline__ bool list_hit_grid(const double* __restrict__ geom, i
             }
         }
     }
-    if (boxes_hit<double>(rg, ro, rd, closest, best, rec)) return true;
+    if (boxes_hit<double>(BoxList{rg.box64, rg.box_index, rg.n_boxes}, ro, rd, closest, best, rec)) return true;
     if (best == 0x7fffffff) return false;
     fill_hit<double>(geom, best, ro, rd, closest, rec);
     return true;
@@ -364,8 +377,8 @@ __device__ __forceinline__ bool scatter(uint32_t kind, const T* __restrict__ mat
 
 // camera.rs:238-262 from the draws already made: `w` = block 0 of the sample's stage-0 stream (uniforms 0, 1 are the
 // offsets in the pixel), (px, py) = the accepted point of random_in_unit_disk (read only with defocus).
-template <typename T>
-__device__ __forceinline__ void get_ray_with(const CamDev<T>& cam, int32_t i, int32_t j, const uint32_t (&w)[4], T px, T py,
+template <typename T, typename Cam> // Cam: a CamDev<T>, in whichever address space it lives
+__device__ __forceinline__ void get_ray_with(const Cam& cam, int32_t i, int32_t j, const uint32_t (&w)[4], T px, T py,
                                              V3<T>& ro, V3<T>& rd) {
     const T ox = u01<T>(w[0]) - (T)0.5, oy = u01<T>(w[1]) - (T)0.5;
     const V3<T> p00 = {cam.p00[0], cam.p00[1], cam.p00[2]};
@@ -643,32 +656,56 @@ static_assert(sizeof(RingEntry) == 32, "ring entries are 32 bytes apart");
 constexpr uint32_t kFifoSlots = 16; // chunks a wave may have grabbed and not begun to retire
 
 #ifndef DRAY_F64_WAVES_PER_EU
-#define DRAY_F64_WAVES_PER_EU 3
+#define DRAY_F64_WAVES_PER_EU 4
 #endif
+
+// Everything a launch of the stream kernel is given.  The kernel reads it where it is used, straight from the
+// kernel-argument segment (scalar loads), instead of holding all of it in scalar registers for the whole launch.
+struct F64Args {
+    CamDev<double> cam;
+    const double* geom;
+    const double* mat;
+    const uint32_t* kind;
+    int32_t n;
+    RefGrid rg;
+    Partition part;
+    RngKey key;
+    uint32_t* color;
+    double* raw;
+    int32_t* count;
+    DeviceCounters* counters;
+    RingEntry* rings;
+    uint32_t chunk_pixels;
+};
+
+// Hides where a pointer came from, so that reads through it are not moved across this point.
+template <typename T>
+__device__ __forceinline__ const DRAY_CONSTANT T* opaque(const DRAY_CONSTANT T* p) {
+    unsigned long long v = (unsigned long long)p;
+    asm volatile("" : "+s"(v));
+    return (const DRAY_CONSTANT T*)v;
+}
 
 template <bool ITERATIVE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DRAY_F64_WAVES_PER_EU, DRAY_F64_WAVES_PER_EU)))
-void render_f64_stream_kernel(CamDev<double> cam, const double* __restrict__ geom, const double* __restrict__ mat,
-                              const uint32_t* __restrict__ kind, int32_t n, RefGrid rg, Partition part, RngKey key,
-                              uint32_t flags, uint32_t* __restrict__ color, double* __restrict__ raw,
-                              int32_t* __restrict__ count, DeviceCounters* counters, RingEntry* rings,
-                              uint32_t chunk_pixels) {
+void render_f64_stream_kernel(F64Args) {
+    const DRAY_CONSTANT F64Args* ka = (const DRAY_CONSTANT F64Args*)__builtin_amdgcn_kernarg_segment_ptr();
     __shared__ uint4 lds_req[4][64];           // coop_draw64: streams handed to server lanes, one set of slots per wave
     __shared__ uint32_t lds_fifo[4][kFifoSlots]; // first pixel of the chunks the wave has grabbed, oldest first
     __shared__ double lds_stage[4][64][3];       // the colours of the samples being retired
     const int lane = (int)(threadIdx.x & 63u), wv = (int)(threadIdx.x >> 6);
-    const GridDev& g = rg.grid;
-    const uint32_t W = (uint32_t)cam.W, spp = (uint32_t)cam.spp, npix = (uint32_t)part.n_rows * W;
+    
+    const uint32_t W = (uint32_t)ka->cam.W, spp = (uint32_t)ka->cam.spp, npix = (uint32_t)ka->part.n_rows * W;
     constexpr bool iterative = ITERATIVE; // how a sample's attenuations are multiplied (camera.rs:130 or :274)
-    RingEntry* ring = rings + (size_t)(blockIdx.x * 4u + (uint32_t)wv) * kF64RingEntries;
-    const int32_t max_steps = g.n[0] + g.n[1] + g.n[2] + 4;
+    RingEntry* ring = ka->rings + (size_t)(blockIdx.x * 4u + (uint32_t)wv) * kF64RingEntries;
+    const int32_t max_steps = ka->rg.grid.n[0] + ka->rg.grid.n[1] + ka->rg.grid.n[2] + 4;
     unsigned long long my_segments = 0;
 
     // where partition pixel `pp` lives: its place in the caller's buffers and its Philox pixel word j * W + i
     auto place_of = [&](uint32_t pp, size_t& out, uint32_t& word) {
         const uint32_t r = pp / W, i = pp - r * W;
-        const uint32_t j = (uint32_t)part.row_begin + r * (uint32_t)part.row_step;
-        out = (size_t)(part.compact ? r : j) * (size_t)W + (size_t)i;
+        const uint32_t j = (uint32_t)ka->part.row_begin + r * (uint32_t)ka->part.row_step;
+        out = (size_t)(ka->part.compact ? r : j) * (size_t)W + (size_t)i;
         word = j * W + i;
     };
 
@@ -702,6 +739,7 @@ void render_f64_stream_kernel(CamDev<double> cam, const double* __restrict__ geo
     unsigned long long clk_t = __builtin_amdgcn_s_memtime();
 #endif
     for (;;) {
+        ka = opaque(ka);
         F64_COUNT(16, 1);                              // turns
         F64_COUNT(17, __popcll(__ballot(has)));        // lanes carrying a sample
         // ---- walk steps, while enough lanes are on their way --------------------------------------------------
@@ -723,7 +761,7 @@ void render_f64_stream_kernel(CamDev<double> cam, const double* __restrict__ geo
                         wk.c[1] += ax == 1 ? dir : 0;
                         wk.c[2] += ax == 2 ? dir : 0;
                         const int32_t moved = ax == 0 ? wk.c[0] : (ax == 1 ? wk.c[1] : wk.c[2]);
-                        const int32_t limit = ax == 0 ? g.n[0] : (ax == 1 ? g.n[1] : g.n[2]);
+                        const int32_t limit = ax == 0 ? ka->rg.grid.n[0] : (ax == 1 ? ka->rg.grid.n[1] : ka->rg.grid.n[2]);
                         const bool inside = moved >= 0 && moved < limit;
                         bool go = inside && !stop;
                         if (go && ++wk.steps > max_steps) { // cannot happen on a straight line: take the whole list
@@ -731,13 +769,13 @@ void render_f64_stream_kernel(CamDev<double> cam, const double* __restrict__ geo
                             go = false;
                         }
                         walking = go;
-                        const uint2 cellrec = g.cells[go ? ((size_t)wk.c[2] * g.n[1] + wk.c[1]) * g.n[0] + wk.c[0] : 0];
+                        const uint2 cellrec = ka->rg.grid.cells[go ? ((size_t)wk.c[2] * ka->rg.grid.n[1] + wk.c[1]) * ka->rg.grid.n[0] + wk.c[0] : 0];
                         wk.e = cellrec.x;
                         wk.e_end = go ? cellrec.x + cellrec.y : cellrec.x;
                     }
                     if (wk.e != wk.e_end) {
-                        const double* eg = rg.entry_geom64 + 4 * (size_t)wk.e;
-                        test64(V3<double>{eg[0], eg[1], eg[2]}, eg[3], rg.entry_index[wk.e], ro, rd, wk);
+                        const double* eg = ka->rg.entry_geom64 + 4 * (size_t)wk.e;
+                        test64(V3<double>{eg[0], eg[1], eg[2]}, eg[3], ka->rg.entry_index[wk.e], ro, rd, wk);
                         ++wk.e;
                     }
                 }
@@ -774,13 +812,13 @@ void render_f64_stream_kernel(CamDev<double> cam, const double* __restrict__ geo
                 if (ret_s == 0u) { // a pixel begins
                     if (ret_dp == ret_np) { // ... and with it a chunk
                         ret_p0 = lds_fifo[wv][begun & (kFifoSlots - 1u)];
-                        ret_np = min(chunk_pixels, npix - ret_p0);
+                        ret_np = min(ka->chunk_pixels, npix - ret_p0);
                         ret_dp = 0u;
                         begun++;
                     }
                     uint32_t word;
                     place_of(ret_p0 + ret_dp, ret_out, word);
-                    acc = raw ? raw[3 * ret_out + (size_t)ch] : 0.;
+                    acc = ka->raw ? ka->raw[3 * ret_out + (size_t)ch] : 0.;
                 }
                 const int take = min(n_ok - k, (int)(spp - ret_s));
 #pragma unroll 8
@@ -790,11 +828,11 @@ void render_f64_stream_kernel(CamDev<double> cam, const double* __restrict__ geo
                 if (ret_s == spp) { // the pixel is complete
                     const double a0 = readlane_f64(acc, 0), a1 = readlane_f64(acc, 1), a2 = readlane_f64(acc, 2);
                     if (lane == 0) {
-                        const int32_t cnt = (count ? count[ret_out] : 0) + (int32_t)spp; // colors.rs:39
+                        const int32_t cnt = (ka->count ? ka->count[ret_out] : 0) + (int32_t)spp; // colors.rs:39
                         const double denom = cnt != 0 ? (double)cnt : 1.;                 // colors.rs:40
-                        color[ret_out] = pack_argb(a0 / denom, a1 / denom, a2 / denom);
-                        if (raw) { raw[3 * ret_out + 0] = a0; raw[3 * ret_out + 1] = a1; raw[3 * ret_out + 2] = a2; }
-                        if (count) count[ret_out] = cnt;
+                        ka->color[ret_out] = pack_argb(a0 / denom, a1 / denom, a2 / denom);
+                        if (ka->raw) { ka->raw[3 * ret_out + 0] = a0; ka->raw[3 * ret_out + 1] = a1; ka->raw[3 * ret_out + 2] = a2; }
+                        if (ka->count) ka->count[ret_out] = cnt;
                     }
                     ret_s = 0u;
                     ret_dp++;
@@ -806,28 +844,30 @@ void render_f64_stream_kernel(CamDev<double> cam, const double* __restrict__ geo
 
         F64_CLOCK(3);
         // ---- lanes whose walk is over: the hit (hittable_list.rs:60-74 / sphere.rs:49-55), or the sky -----------
+        // (which sphere or box and how far is all that is settled here; point and normal are made where the scatter
+        // needs them, after the wave's draws, so that they do not sit in registers through those)
         const bool ready = has && !walking && !camera;
-        Hit<double> rec = {};
-        bool scatters = false, ended = false;
+        bool scatters = false, ended = false, is_box = false;
         uint32_t mk = 0xFFu;
         V3<double> c = {0., 0., 0.};
         if (ready) {
             if (depth <= 0 || dead) { // camera.rs:265-267 / :120-123, or absorbed (camera.rs:276): black
                 ended = true;
             } else {
-                bool hit;
-                if (fallback) {
-                    hit = list_hit_linear<double>(geom, n, rg, ro, rd, rec);
-                } else if (boxes_hit<double>(rg, ro, rd, wk.closest, wk.best, rec)) {
-                    hit = true;
-                } else if (wk.best == 0x7fffffff) {
-                    hit = false;
-                } else {
-                    fill_hit<double>(geom, wk.best, ro, rd, wk.closest, rec);
-                    hit = true;
+                if (fallback) { // the reference's own scan, hittable_list.rs:65-70
+                    wk.closest = INFINITY;
+                    wk.best = 0x7fffffff;
+                    for (int32_t k = 0; k < ka->n; ++k) {
+                        double root;
+                        if (sphere_root<double>(ka->geom, k, ro, rd, root) && root < wk.closest) {
+                            wk.closest = root;
+                            wk.best = k;
+                        }
+                    }
                 }
-                if (hit) {
-                    mk = kind[rec.index];
+                is_box = boxes_closest<double>(BoxList{ka->rg.box64, ka->rg.box_index, ka->rg.n_boxes}, ro, rd, wk.closest, wk.best);
+                if (wk.best != 0x7fffffff) {
+                    mk = ka->kind[wk.best];
                     scatters = true;
                 } else {
                     V3<double> ud = vunit(rd); // camera.rs:279-281
@@ -852,7 +892,7 @@ void render_f64_stream_kernel(CamDev<double> cam, const double* __restrict__ geo
                     for (int u = 0; u < 4; ++u) q[u] = stack[sp - 1 - (u < n4 ? u : 0)];
                     V3<double> al[4];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) al[u] = {mat[4 * q[u]], mat[4 * q[u] + 1], mat[4 * q[u] + 2]};
+                    for (int u = 0; u < 4; ++u) al[u] = {ka->mat[4 * q[u]], ka->mat[4 * q[u] + 1], ka->mat[4 * q[u] + 2]};
 #pragma unroll
                     for (int u = 0; u < 4; ++u)
                         if (u < n4) c = vmul(al[u], c);
@@ -876,7 +916,7 @@ void render_f64_stream_kernel(CamDev<double> cam, const double* __restrict__ geo
                 if (iss_q == iss_n && !exhausted) { // the next chunk of pixels
                     if (grabbed - begun == kFifoSlots) break;
                     unsigned long long base = 0ull;
-                    if (lane == 0) base = atomicAdd(&counters->next_item, (unsigned long long)chunk_pixels);
+                    if (lane == 0) base = atomicAdd(&ka->counters->next_item, (unsigned long long)ka->chunk_pixels);
                     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)base);
                     const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
                     if (hi != 0u || lo >= npix) {
@@ -886,7 +926,7 @@ void render_f64_stream_kernel(CamDev<double> cam, const double* __restrict__ geo
                         grabbed++;
                         iss_p0 = lo;
                         iss_q = 0u;
-                        iss_n = min(chunk_pixels, npix - lo) * spp;
+                        iss_n = min(ka->chunk_pixels, npix - lo) * spp;
                     }
                 }
                 if (exhausted) break;
@@ -917,11 +957,11 @@ void render_f64_stream_kernel(CamDev<double> cam, const double* __restrict__ geo
         F64_CLOCK(4);
         // ---- the first uniforms of the next step, and the rejection samplers, by the whole wave -----------------
         const bool draws = scatters || camera;
-        const Stream st = {key.k0, key.k1, pw, key.sample_offset + smp, camera ? 0u : (uint32_t)(cam.max_depth - depth + 1)};
+        const Stream st = {ka->key.k0, ka->key.k1, pw, ka->key.sample_offset + smp, camera ? 0u : (uint32_t)(ka->cam.max_depth - depth + 1)};
         uint32_t w[4] = {0u, 0u, 0u, 0u};
         if (draws) st.block(0, w);
         const uint32_t draw = (scatters && (mk == DRAY_MAT_LAMBERTIAN || mk == DRAY_MAT_METAL)) ? (uint32_t)kDraw64UnitVector
-                              : (camera && cam.defocus != 0)                                      ? (uint32_t)kDraw64UnitDisk
+                              : (camera && ka->cam.defocus != 0)                                      ? (uint32_t)kDraw64UnitDisk
                                                                                                   : (uint32_t)kDraw64None;
         F64_CLOCK(5);
         const Drawn got = coop_draw64(st, w, draw, lds_req[wv], lane);
@@ -930,9 +970,12 @@ void render_f64_stream_kernel(CamDev<double> cam, const double* __restrict__ geo
         // ---- scatter: material.rs -------------------------------------------------------------------------
         bool fresh = false;
         if (scatters) {
+            Hit<double> rec; // sphere.rs:49-55
+            if (is_box) box_record<double>(ro, rd, wk.closest, wk.best, rec);
+            else fill_hit<double>(ka->geom, wk.best, ro, rd, wk.closest, rec);
             V3<double> so = ro, sd;
             const bool scattered = scatter_with<double>(
-                mk, mat + 4 * rec.index, rd, rec,
+                mk, ka->mat + 4 * rec.index, rd, rec,
                 [&]() { // vec3.rs:82 for the accepted attempt
                     const uint32_t ww[4] = {got.a, got.b, got.c, 0u};
                     V3<double> p;
@@ -945,7 +988,7 @@ void render_f64_stream_kernel(CamDev<double> cam, const double* __restrict__ geo
                 const bool white = mk == DRAY_MAT_DIELECTRIC || mk == DRAY_MAT_TRANSPARENT; // attenuation (1, 1, 1)
                 if constexpr (iterative) {
                     V3<double> al = white ? V3<double>{1., 1., 1.}
-                                          : V3<double>{mat[4 * rec.index], mat[4 * rec.index + 1], mat[4 * rec.index + 2]};
+                                          : V3<double>{ka->mat[4 * rec.index], ka->mat[4 * rec.index + 1], ka->mat[4 * rec.index + 2]};
                     att = vmul(att, al); // camera.rs:130
                 } else if (!white) {
                     stack[sp++] = (uint32_t)rec.index; // a product with (1,1,1) is exact, so those are skipped
@@ -965,9 +1008,9 @@ void render_f64_stream_kernel(CamDev<double> cam, const double* __restrict__ geo
             double px = 0., py = 0.;
             unit_disk_attempt<double>(got.a, got.b, px, py);
             const uint32_t j = pw / W, i = pw - j * W;
-            get_ray_with<double>(cam, (int32_t)i, (int32_t)j, w, px, py, ro, rd);
+            get_ray_with<double>(ka->cam, (int32_t)i, (int32_t)j, w, px, py, ro, rd);
             att = {1., 1., 1.};
-            depth = cam.max_depth;
+            depth = ka->cam.max_depth;
             sp = 0;
             camera = false;
             fresh = depth > 0;
@@ -991,11 +1034,11 @@ void render_f64_stream_kernel(CamDev<double> cam, const double* __restrict__ geo
                 fallback = true;
             } else {
                 {
-                    const DRAY_CONSTANT double* ag = as_constant(rg.always_geom64);
-                    const DRAY_CONSTANT int32_t* ai = as_constant(rg.always_index);
+                    const DRAY_CONSTANT double* ag = as_constant(ka->rg.always_geom64);
+                    const DRAY_CONSTANT int32_t* ai = as_constant(ka->rg.always_index);
                     // the wide and the loose spheres (scalar loads), four at a time so that their chains of f64
                     // operations run side by side
-                    const int32_t n_always = rg.n_always;
+                    const int32_t n_always = ka->rg.n_always;
                     int32_t q = 0;
                     for (; q + 4 <= n_always; q += 4) {
 #pragma unroll
@@ -1006,15 +1049,15 @@ void render_f64_stream_kernel(CamDev<double> cam, const double* __restrict__ geo
                     for (; q < n_always; ++q)
                         test64(V3<double>{ag[4 * q], ag[4 * q + 1], ag[4 * q + 2]}, ag[4 * q + 3], ai[q], ro, rd, wk);
                 }
-                if (g.n[0] > 0) {
+                if (ka->rg.grid.n[0] > 0) {
                     double t_in = 0., t_out = INFINITY, bmax = 0.;
                     bool inside_slabs = true;
 #pragma unroll
                     for (int a = 0; a < 3; ++a) {
                         if (fabs(d[a]) > 1e-250) {
                             const double inv = 1.0 / d[a];
-                            wk.A[a] = (double)g.cell[a] * inv;
-                            const double t0 = ((double)g.lo[a] - o[a]) * inv, t1 = ((double)g.hi[a] - o[a]) * inv;
+                            wk.A[a] = (double)ka->rg.grid.cell[a] * inv;
+                            const double t0 = ((double)ka->rg.grid.lo[a] - o[a]) * inv, t1 = ((double)ka->rg.grid.hi[a] - o[a]) * inv;
                             wk.B[a] = d[a] >= 0. ? t0 + wk.A[a] : t0; // leaving cell k towards larger indices happens at plane k + 1
                             t_in = fmax(t_in, fmin(t0, t1));
                             t_out = fmin(t_out, fmax(t0, t1));
@@ -1022,17 +1065,17 @@ void render_f64_stream_kernel(CamDev<double> cam, const double* __restrict__ geo
                         } else { // parallel to the axis' planes: never crosses one; misses the grid if outside its slab
                             wk.A[a] = 0.;
                             wk.B[a] = INFINITY;
-                            if (o[a] < (double)g.lo[a] || o[a] > (double)g.hi[a]) inside_slabs = false;
+                            if (o[a] < (double)ka->rg.grid.lo[a] || o[a] > (double)ka->rg.grid.hi[a]) inside_slabs = false;
                         }
                     }
                     wk.slack = bmax * 1e-9;
                     if (inside_slabs && t_in <= t_out + wk.slack) {
 #pragma unroll
                         for (int a = 0; a < 3; ++a) {
-                            const double at = floor((o[a] + d[a] * t_in - (double)g.lo[a]) * (double)g.inv_cell[a]);
-                            wk.c[a] = (int32_t)fmin(fmax(at, 0.), (double)(g.n[a] - 1));
+                            const double at = floor((o[a] + d[a] * t_in - (double)ka->rg.grid.lo[a]) * (double)ka->rg.grid.inv_cell[a]);
+                            wk.c[a] = (int32_t)fmin(fmax(at, 0.), (double)(ka->rg.grid.n[a] - 1));
                         }
-                        const uint2 cellrec = g.cells[((size_t)wk.c[2] * g.n[1] + wk.c[1]) * g.n[0] + wk.c[0]];
+                        const uint2 cellrec = ka->rg.grid.cells[((size_t)wk.c[2] * ka->rg.grid.n[1] + wk.c[1]) * ka->rg.grid.n[0] + wk.c[0]];
                         wk.e = cellrec.x;
                         wk.e_end = cellrec.x + cellrec.y;
                         walking = true;
@@ -1050,9 +1093,9 @@ void render_f64_stream_kernel(CamDev<double> cam, const double* __restrict__ geo
 
     // one atomic per wave
     for (int off = 32; off > 0; off >>= 1) my_segments += __shfl_down(my_segments, off, 64);
-    if (lane == 0 && counters) {
-        atomicAdd(&counters->segments, my_segments);
-        atomicAdd(&counters->samples, n_samples);
+    if (lane == 0 && ka->counters) {
+        atomicAdd(&ka->counters->segments, my_segments);
+        atomicAdd(&ka->counters->samples, n_samples);
     }
 }
 
@@ -1213,10 +1256,15 @@ hipError_t launch_render_f64_stream(const CamDev<double>& cam, const SceneDev& s
                                     double* d_raw, int32_t* d_count, DeviceCounters* d_counters, void* rings,
                                     hipStream_t stream) {
     if (!rings || !d_counters) return hipErrorInvalidValue;
+    F64Args args{};
+    args.cam = cam;
+    args.geom = scene.geom64; args.mat = scene.mat64; args.kind = scene.kind; args.n = scene.n;
+    args.rg = ref_grid_of(scene, true);
+    args.part = part; args.key = key;
+    args.color = d_color; args.raw = d_raw; args.count = d_count; args.counters = d_counters;
+    args.rings = (RingEntry*)rings; args.chunk_pixels = plan.chunk_pixels;
     auto launch = [&](auto kernel) {
-        hipLaunchKernelGGL(kernel, dim3((unsigned)plan.grid), dim3(plan.block), 0, stream, cam, scene.geom64, scene.mat64,
-                           scene.kind, scene.n, ref_grid_of(scene, true), part, key, flags, d_color, d_raw, d_count, d_counters,
-                           (RingEntry*)rings, plan.chunk_pixels);
+        hipLaunchKernelGGL(kernel, dim3((unsigned)plan.grid), dim3(plan.block), 0, stream, args);
     };
     if (flags & DRAY_FLAG_ITERATIVE_PRODUCT) launch(render_f64_stream_kernel<true>);
     else launch(render_f64_stream_kernel<false>);
