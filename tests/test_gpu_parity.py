@@ -1118,6 +1118,52 @@ def test_rccl_gather_on_one_gpu(dray, gpu):
         dist.destroy_process_group()
 
 
+def test_f64_stream_kernel_shapes_of_work(dray, gpu, oracle):
+    """The f64 kernel that runs the frame as a stream of samples (the default of DRAY_MODE_F64) against the
+    one-thread-per-pixel kernel and the oracle, bit for bit, where its bookkeeping is under strain: one sample per
+    pixel (a chunk of 256 pixels per grab), more samples per pixel than a chunk holds (one pixel per grab), a frame
+    smaller than one chunk, a frame of one pixel column, row partitions (strided and compact), sums continued over
+    two calls, and paths of up to 100 segments whose neighbours finish hundreds of samples before they do (the
+    ring of finished samples fills up behind them)."""
+    final, three, glass = dray.scene_final(1), dray.scene_three_spheres(), dray.scene_glass_metal(1)
+    cases = [("1spp", final, dict(width=160, spp=1, depth=50)), ("300spp", final, dict(width=24, spp=300, depth=50)),
+             ("tiny", three, dict(width=5, spp=3, depth=10)), ("column", final, dict(width=1, spp=40, depth=20)),
+             ("deep", glass, dict(width=40, spp=700, depth=100)), ("odd", final, dict(width=97, spp=37, depth=12))]
+    for name, spheres, kw in cases:
+        cam = (dray.camera_three_spheres if spheres is three else dray.camera_final)(**kw)
+        cam.mode = dray.MODE_F64
+        for flags in (0, dray.FLAG_ITERATIVE_PRODUCT):
+            cam.flags = flags
+            a = render_gpu(dray, gpu, spheres, cam, seed=29)                             # stream of samples
+            b = render_gpu(dray, gpu, spheres, cam, seed=29, variant=dray.SCAN_HYBRID)   # one thread per pixel
+            assert (a[0] == b[0]).all() and (a[1] == b[1]).all() and (a[2] == b[2]).all(), (name, flags)
+            assert a[3].segments == b[3].segments and a[3].samples == b[3].samples, (name, flags)
+        if name in ("1spp", "tiny", "column", "odd"):
+            cam.flags = 0
+            ocol, oraw, ocnt, ost = oracle.render(ocam_from(oracle, cam), spheres, seed=29, threads=8)
+            a = render_gpu(dray, gpu, spheres, cam, seed=29)
+            assert (a[0] == ocol).all() and (a[1] == oraw).all() and a[3].segments == ost.segments, name
+    # row partitions and a second call that adds to the first
+    cam = dray.camera_final(width=64, spp=9, depth=30)
+    cam.mode, cam.flags = dray.MODE_F64, 0
+    H = cam.initialize().image_height
+    whole = render_gpu(dray, gpu, final, cam, seed=31)
+    scene = gpu.DeviceScene(final, 0)
+    color, raw, count = gpu.alloc_buffers(cam, 0)
+    segs = 0
+    for r in range(3):
+        segs += gpu.render_device(cam, scene, color, raw, count, seed=31, row_begin=r, row_step=3).segments
+    assert (gpu.color_to_numpy(color) == whole[0]).all() and (raw.cpu().numpy() == whole[1]).all() and segs == whole[3].segments
+    cam.samples_per_pixel = 4
+    color, raw, count = gpu.alloc_buffers(cam, 0)
+    gpu.render_device(cam, scene, color, raw, count, seed=31)
+    cam.samples_per_pixel = 5
+    gpu.render_device(cam, scene, color, raw, count, seed=31, sample_offset=4)
+    scene.close()
+    assert (gpu.color_to_numpy(color) == whole[0]).all() and (raw.cpu().numpy() == whole[1]).all()
+    assert (count.cpu().numpy()[:H] == 9).all()
+
+
 def test_headline_frame_f32_against_f64_kernel_and_oracle(dray, gpu, oracle):
     """The measured configuration at full size: final scene, 1200 x 675, 500 samples per pixel, depth 50.  The oracle
     cannot render 405 M samples in seconds, so the chain is: every 45th row of the f64 reference-order kernel's frame
