@@ -173,6 +173,7 @@ void scene_free(dray_scene* s) {
     (void)hipFree(d.narrow_index); (void)hipFree(d.wide_index);
     (void)hipFree(d.grid_cells); (void)hipFree(d.grid_entry_geom); (void)hipFree(d.grid_entry_pos); (void)hipFree(d.grid_loose);
     (void)hipFree(d.box64); (void)hipFree(d.box_index);
+    (void)hipFree(d.loose_geom); (void)hipFree(d.loose_index); (void)hipFree(d.wide_geom64);
     (void)hipFree(d.entry_geom64); (void)hipFree(d.entry_index); (void)hipFree(d.always_geom64); (void)hipFree(d.always_index);
     (void)hipFree(s->d_counters); (void)hipFree(s->d_accum); (void)hipFree(s->d_rings);
     for (auto& e : s->ev)
@@ -505,6 +506,27 @@ int scene_create_impl(const dray_sphere* sp, size_t n, int32_t device, dray_scen
         for (size_t k = 0; k < ai.size(); ++k)
             for (int q = 0; q < 4; ++q) ag[4 * k + q] = g64[4 * (size_t)ai[k] + q];
         d.n_always = (int32_t)ai.size();
+        // ... and for the f32 grid scan: the loose spheres' rows in fours, the wide spheres' f64 rows side by side
+        std::vector<float> lg;
+        std::vector<int32_t> li;
+        for (int32_t p : grid.loose) {
+            for (int q = 0; q < 4; ++q) lg.push_back(ng[4 * (size_t)p + q]);
+            li.push_back(nidx[p]);
+        }
+        while (li.size() % 4 != 0) { // never hit: the discriminant is -1e30 + h*h - |oc|^2 < 0
+            lg.push_back(0.f); lg.push_back(0.f); lg.push_back(0.f); lg.push_back(-1e30f);
+            li.push_back(0x3fffffff);
+        }
+        std::vector<double> wg(4 * widx.size());
+        for (size_t k = 0; k < widx.size(); ++k)
+            for (int q = 0; q < 4; ++q) wg[4 * k + q] = g64[4 * (size_t)widx[k] + q];
+        if ((rc = upload(&d.loose_geom, lg)) || (rc = upload(&d.loose_index, li)) || (rc = upload(&d.wide_geom64, wg))) {
+            scene_free(s);
+            return rc;
+        }
+        d.grid.loose_geom = (const float4*)d.loose_geom;
+        d.grid.loose_index = d.loose_index;
+        d.grid.n_loose_padded = (int32_t)li.size();
         if ((rc = upload(&d.entry_geom64, eg)) || (rc = upload(&d.entry_index, ei)) || (rc = upload(&d.always_geom64, ag)) ||
             (rc = upload(&d.always_index, ai))) {
             scene_free(s);
@@ -536,6 +558,8 @@ int scene_create_impl(const dray_sphere* sp, size_t n, int32_t device, dray_scen
     d.f32.narrow_index = d.narrow_index;
     d.f32.wide_index = d.wide_index;
     d.f32.geom64 = d.geom64;
+    d.f32.wide_geom64 = d.wide_geom64;
+    d.grid.entry_index = d.entry_index;
     d.f32.geom32 = (const float4*)d.geom32;
     d.f32.mat32 = (const float4*)d.mat32;
     d.f32.kind = d.kind32;

@@ -39,6 +39,7 @@ struct F32Tables {
     const int32_t* narrow_index = nullptr; // position of a narrow sphere in the caller's list
     const int32_t* wide_index = nullptr;   // positions of the wide spheres, ascending
     const double* geom64 = nullptr;        // n x 4: cx, cy, cz, radius
+    const double* wide_geom64 = nullptr;   // n_wide x 4: the wide spheres' rows of geom64, one after the other
     const float4* geom32 = nullptr;        // n: cx, cy, cz, radius
     const float4* mat32 = nullptr;         // n: albedo rgb, fuzz or refraction index
     const uint32_t* kind = nullptr;        // n: material kind
@@ -61,6 +62,11 @@ struct GridDev {
     const float4* entry_geom = nullptr; // per entry: cx, cy, cz, r*r (the sphere's narrow_geom row)
     const int32_t* entry_pos = nullptr; // per entry: the sphere's position in the narrow table; ascending in a cell
     const int32_t* loose = nullptr;     // narrow positions of the loose spheres, ascending
+    // the same lists as the f32 grid scan reads them: a test costs one load, and a hit names the list entry at once
+    const int32_t* entry_index = nullptr;  // per entry: the sphere's position in the caller's list
+    const float4* loose_geom = nullptr;    // the loose spheres' exact-table rows, padded to a multiple of four with
+    const int32_t* loose_index = nullptr;  // ... rows no ray hits; their positions in the caller's list
+    int32_t n_loose_padded = 0;
 };
 
 // Sphere tables in device memory (owned by the scene).
@@ -91,6 +97,9 @@ struct SceneDev {
     float* grid_entry_geom = nullptr;
     int32_t* grid_entry_pos = nullptr;
     int32_t* grid_loose = nullptr;
+    float* loose_geom = nullptr;
+    int32_t* loose_index = nullptr;
+    double* wide_geom64 = nullptr;
     size_t grid_entries = 0;
     GridDev grid{};
     // the same lists for the f64 stream kernel, with the f64 geometry beside them so that a test costs one load:

@@ -66,6 +66,18 @@ constexpr int kWalkQuorum = DRAY_WALK_QUORUM;     // grid scan: lanes that must 
 #else
 #define DRAY_MARK(name)
 #endif
+// DRAY_SECTION_CLOCKS (tools/f32_clocks.py): a wave adds up the shader clocks it spends in each section.
+#ifdef DRAY_SECTION_CLOCKS
+__device__ unsigned long long dray_section_clocks[16];
+#define DRAY_CLOCK(slot)                                               \
+    do {                                                               \
+        const unsigned long long now__ = __builtin_amdgcn_s_memtime(); \
+        clk[slot] += now__ - clk_t;                                    \
+        clk_t = now__;                                                 \
+    } while (0)
+#else
+#define DRAY_CLOCK(slot)
+#endif
 #ifdef DRAY_SECTION_COUNTERS
 __device__ unsigned long long dray_section_counts[16];
 #define DRAY_COUNT(slot, n) (sec[slot] += (unsigned long long)(n))
@@ -300,8 +312,8 @@ struct Walk {
     float c[3];        // current cell (small integers, exact in f32)
     uint32_t e, e_end; // entries of the current cell still to test
     // Closest accepted root so far as one ordered key: bits of t (positive floats order like integers) in the high
-    // word, then the sphere's narrow position and the far-root flag.  The minimum key is the scalar scan's answer:
-    // smallest t, on equal t the sphere inserted first (hittable_list.rs:65-70).
+    // word, then the sphere's position in the caller's list and the far-root flag.  The minimum key is the scalar
+    // scan's answer: smallest t, on equal t the sphere inserted first (hittable_list.rs:65-70).
     unsigned long long best;
 };
 
@@ -325,12 +337,14 @@ __device__ __forceinline__ void walk_test(Walk& w, const V4 s, int32_t pos, cons
 }
 
 // Tests the loose spheres, then places the ray in its first cell.  Returns false when there is nothing to walk.
-__device__ __forceinline__ bool walk_begin(ConstPtr<GridDev> gp, ConstPtr<V4> narrow_geom, const PathRay& ray, Walk& w) {
+__device__ __forceinline__ bool walk_begin(ConstPtr<GridDev> gp, const PathRay& ray, Walk& w) {
     const DRAY_CONSTANT GridDev& g = *gp;
     w.best = kNoHit;
-    for (int32_t k = 0; k < g.n_loose; ++k) { // wave-uniform
-        const int32_t pos = g.loose[k];
-        walk_test(w, narrow_geom[pos], pos, ray);
+    ConstPtr<V4> loose_geom = as_constant((const V4*)g.loose_geom);
+    ConstPtr<int32_t> loose_index = as_constant(g.loose_index);
+    for (int32_t k = 0; k < g.n_loose_padded; k += 4) { // wave-uniform; four rows and their list positions per scalar load
+#pragma unroll
+        for (int32_t u = 0; u < 4; ++u) walk_test(w, loose_geom[k + u], loose_index[k + u], ray);
     }
     if (g.n[0] == 0) return false;
     const float o[3] = {ray.o.x, ray.o.y, ray.o.z}, d[3] = {ray.d.x, ray.d.y, ray.d.z};
@@ -373,7 +387,7 @@ struct GridRegs {
     float n0, n1, n2; // cells per axis (at most 256: products and sums below are exact in f32)
     const uint2* cells;
     const V4* entry_geom;
-    const int32_t* entry_pos;
+    const int32_t* entry_index;
 };
 
 // One step of a walking lane: leave a finished cell (or stop), then test one listed sphere.  Returns false when
@@ -402,7 +416,7 @@ __device__ __forceinline__ bool walk_step(const GridRegs& g, const PathRay& ray,
         w.e_end = go ? rec.x + rec.y : rec.x;
     }
     if (w.e != w.e_end) {
-        walk_test(w, g.entry_geom[w.e], g.entry_pos[w.e], ray);
+        walk_test(w, g.entry_geom[w.e], g.entry_index[w.e], ray);
         ++w.e;
     }
     return go;
@@ -417,6 +431,7 @@ struct F32Args {
     const int32_t* narrow_index;
     const int32_t* wide_index;
     const double* geom64;
+    const double* wide_geom64;
     const V4* geom32;
     const V4* mat32;
     const uint32_t* kind;
@@ -552,8 +567,13 @@ __device__ __forceinline__ void render_f32_body() {
 #ifdef DRAY_SECTION_COUNTERS
     unsigned long long sec[16] = {};
 #endif
+#ifdef DRAY_SECTION_CLOCKS
+    unsigned long long clk[16] = {};
+    unsigned long long clk_t = __builtin_amdgcn_s_memtime();
+#endif
     for (;;) {
         a = opaque(a);
+        DRAY_CLOCK(9); // loop edge (and, on the first turn, the kernel's entry)
 
         // ---- closest hit over the sphere list: hittable_list.rs:60-74 ---------------------------
         DRAY_MARK("A_fresh_setup");
@@ -613,7 +633,7 @@ __device__ __forceinline__ void render_f32_body() {
             if constexpr (SCAN == kScanHybrid)
                 scan_hybrid(lds_xy, as_constant(a->filter_zn), as_constant(a->narrow_geom), a->n_narrow_padded, nray, sb);
             else if constexpr (SCAN == kScanGrid)
-                walking = walk_begin(&a->grid, as_constant(a->narrow_geom), nray, walk);
+                walking = walk_begin(&a->grid, nray, walk);
             else
                 scan_scalar(as_constant(a->narrow_geom), a->n_narrow_padded, nray, sb);
             fresh = false;
@@ -622,9 +642,10 @@ __device__ __forceinline__ void render_f32_body() {
             // walk until fewer than a quorum of lanes are still on their way (all of them once the queue is empty)
             const int quorum = exhausted ? 1 : kWalkQuorum;
             const GridRegs gr = {(float)a->grid.n[0], (float)a->grid.n[1], (float)a->grid.n[2], a->grid.cells,
-                                 (const V4*)a->grid.entry_geom, a->grid.entry_pos};
+                                 (const V4*)a->grid.entry_geom, a->grid.entry_index};
             PathRay nray = ray;
             nray.tmin = fmaxf(ray.tmin, 0.f); // see the origin's move above
+            DRAY_CLOCK(0);
             DRAY_MARK("B_walk_steps");
             do { // two steps per count: the count is scalar-unit work every walking lane waits for
                 DRAY_COUNT(2, 2);                                  // walk steps (wave level)
@@ -634,6 +655,7 @@ __device__ __forceinline__ void render_f32_body() {
                 n_steps += 2u;
             } while (__popcll(__ballot(walking)) >= quorum);
         }
+        DRAY_CLOCK(1);
         DRAY_MARK("C_hit");
 
         // ---- the hit: winner of the narrow scan against the wide spheres, point and normal --------------
@@ -653,29 +675,9 @@ __device__ __forceinline__ void render_f32_body() {
             const float tmin = ray.tmin;
             float best = sb.t;
             // Re-evaluate the winner from the perpendicular remainder |oc - h d|, which does not cancel.
-#ifdef DRAY_F64_WINNER
-            // Experiment (tools/build_f64_winner_lib.sh): root, point and normal of the winning narrow sphere in f64 from
-            // the f32 ray.  Measured on the headline frame against the f64 kernel: see the design notes; not kept.
             if (sb.pos >= 0) {
-                bidx = as_constant(a->narrow_index)[sb.pos];
-                ConstPtr<double> g64 = as_constant(a->geom64);
-                const double cx = g64[4 * bidx], cy = g64[4 * bidx + 1], cz = g64[4 * bidx + 2], rad = g64[4 * bidx + 3];
-                const double ocx = cx - (double)ox, ocy = cy - (double)oy, ocz = cz - (double)oz;
-                const double ddx = dx, ddy = dy, ddz = dz;
-                const double aa = fma(ddz, ddz, fma(ddy, ddy, ddx * ddx));
-                const double h = fma(ddz, ocz, fma(ddy, ocy, ddx * ocx));
-                const double cc = fma(ocz, ocz, fma(ocy, ocy, fma(ocx, ocx, -(rad * rad))));
-                const double disc = fmax(fma(h, h, -(aa * cc)), 0.);
-                const double sq = sqrt(disc);
-                const double t = (sb.far ? h + sq : h - sq) / aa;
-                best = (float)t;
-                const double px = fma(t, ddx, (double)ox), py = fma(t, ddy, (double)oy), pz = fma(t, ddz, (double)oz);
-                hp = {(float)px, (float)py, (float)pz};
-                hn = {(float)((px - cx) / rad), (float)((py - cy) / rad), (float)((pz - cz) / rad)};
-            }
-#else
-            if (sb.pos >= 0) {
-                bidx = as_constant(a->narrow_index)[sb.pos];
+                if constexpr (SCAN == kScanGrid) bidx = sb.pos; // the walk's key names the list entry itself
+                else bidx = as_constant(a->narrow_index)[sb.pos];
                 const V4 s = as_constant(a->geom32)[bidx];
                 const F3 oc = {s.x - ox, s.y - oy, s.z - oz};
                 const float h = dot(oc, ray.d);
@@ -687,17 +689,16 @@ __device__ __forceinline__ void render_f32_body() {
                 const float ir = rcp(s.w);
                 hn = {(hp.x - s.x) * ir, (hp.y - s.y) * ir, (hp.z - s.z) * ir}; // sphere.rs:52
             }
-#endif
             const int32_t n_wide = a->n_wide;
             ConstPtr<int32_t> wide_index = as_constant(a->wide_index);
-            ConstPtr<double> geom64 = as_constant(a->geom64);
+            ConstPtr<double> geom64 = as_constant(a->wide_geom64); // the wide spheres' rows, side by side
             for (int32_t wq = 0; wq < n_wide; ++wq) {
                 // sphere.rs:28-57 in f64 for a sphere too large for f32: the cancelling terms (oc, |oc|^2 - r^2,
                 // the discriminant, the hit point relative to the centre) are f64; divisions are avoided
                 // (1/|d|^2 = 2 - |d|^2 to 1e-14 because d is unit to f32 rounding; sqrt = f32 estimate + one Newton step)
                 const int32_t idx = wide_index[wq];
-                const double cx = geom64[4 * idx + 0], cy = geom64[4 * idx + 1], cz = geom64[4 * idx + 2];
-                const double rad = geom64[4 * idx + 3];
+                const double cx = geom64[4 * wq + 0], cy = geom64[4 * wq + 1], cz = geom64[4 * wq + 2];
+                const double rad = geom64[4 * wq + 3];
                 const double ocx = cx - (double)ox, ocy = cy - (double)oy, ocz = cz - (double)oz;
                 const double ddx = dx, ddy = dy, ddz = dz;
                 const double aa = fma(ddz, ddz, fma(ddy, ddy, ddx * ddx));
@@ -738,6 +739,7 @@ __device__ __forceinline__ void render_f32_body() {
 
         // ---- paths that end here without scattering: sky (camera.rs:279-281), an absorbing material
         // (material.rs:13-19), or no depth left for the scattered ray (camera.rs:265-267: its colour is 0) ------
+        DRAY_CLOCK(2);
         DRAY_MARK("D_deposit");
         DRAY_COUNT(4, __popcll(__ballot(shading)));                // lanes shading
         DRAY_COUNT(5, __ballot(shading) != 0ull ? 1 : 0);          // iterations with a lane shading
@@ -754,6 +756,7 @@ __device__ __forceinline__ void render_f32_body() {
         // ---- refill: camera.rs:217-224.  Idle lanes (their path just ended, or the launch just began) take the
         // pool's next samples; their camera ray is made further down, so that its first Philox block is evaluated
         // together with the scattering lanes' first block ----------------------------------------------
+        DRAY_CLOCK(3);
         DRAY_MARK("E_refill");
         bool need = stage == 0 && !camera;
         unsigned long long want = __ballot(need);
@@ -845,6 +848,7 @@ __device__ __forceinline__ void render_f32_body() {
         // Dialectric: the reflect/refract uniform), a lane with a new sample with block 0 of stage 0 (pixel offsets,
         // first aperture attempt): one evaluation serves both.  The further attempts of the unit-vector rejection
         // sampler, and of the aperture's, are shared out over all 64 lanes, busy or not (coop_draw).
+        DRAY_CLOCK(4);
         DRAY_MARK("F_philox_block0");
         const bool scatters = shading && !ends_now;
         const bool wants_vector = scatters && (mk == DRAY_MAT_LAMBERTIAN || mk == DRAY_MAT_METAL);
@@ -856,6 +860,7 @@ __device__ __forceinline__ void render_f32_body() {
         // defocus_angle > 0 (camera.rs:247)
         const uint32_t draw = wants_vector ? (uint32_t)kDrawUnitVector
                                            : (camera && a->cam.defocus != 0) ? (uint32_t)kDrawUnitDisk : (uint32_t)kDrawNone;
+        DRAY_CLOCK(5);
         DRAY_MARK("G_coop_draw");
 #ifdef DRAY_SECTION_COUNTERS
         uint32_t rounds = 0u;
@@ -866,6 +871,7 @@ __device__ __forceinline__ void render_f32_body() {
 #else
         const F3 ruv = coop_draw(st, w, draw, lds_req[wv], lane);
 #endif
+        DRAY_CLOCK(6);
         DRAY_MARK("H_scatter");
 
         // ---- scatter: material.rs ---------------------------------------------------------------------
@@ -915,6 +921,7 @@ __device__ __forceinline__ void render_f32_body() {
         }
 
         // ---- camera ray of a new sample: camera.rs:238-262 --------------------------------------------
+        DRAY_CLOCK(7);
         DRAY_MARK("I_camera_ray");
         if (camera) {
             camera_ray(&a->cam, (int32_t)ray.o.x, (int32_t)ray.o.y, w, ruv, ray);
@@ -923,9 +930,15 @@ __device__ __forceinline__ void render_f32_body() {
             fresh = true;
             camera = false;
         }
+        DRAY_CLOCK(8);
     }
 
     DRAY_MARK("Z_exit");
+#ifdef DRAY_SECTION_CLOCKS
+    if (lane == 0)
+        for (int q = 0; q < 16; ++q)
+            if (clk[q]) atomicAdd(&dray_section_clocks[q], clk[q]);
+#endif
     retire_slots(0u, 0u, (uint32_t)kSlots, false);
 #ifdef DRAY_SECTION_COUNTERS
     if (lane == 0)
@@ -1073,7 +1086,7 @@ hipError_t launch_render_f32(const CamDev<float>& cam, const SceneDev& scene, co
     args.cam = cam;
     args.narrow_geom = (const V4*)t.narrow_geom; args.filter_xy = (const V4*)t.filter_xy; args.filter_zn = (const V4*)t.filter_zn;
     args.narrow_index = t.narrow_index; args.wide_index = t.wide_index;
-    args.geom64 = t.geom64; args.geom32 = (const V4*)t.geom32; args.mat32 = (const V4*)t.mat32; args.kind = t.kind;
+    args.geom64 = t.geom64; args.wide_geom64 = t.wide_geom64; args.geom32 = (const V4*)t.geom32; args.mat32 = (const V4*)t.mat32; args.kind = t.kind;
     args.n_narrow_padded = t.n_narrow_padded; args.n_wide = t.n_wide;
     args.box64 = scene.box64; args.box_index = scene.box_index; args.n_boxes = scene.n_boxes;
     for (int q = 0; q < 4; ++q) args.bound[q] = t.bound[q];
@@ -1093,6 +1106,15 @@ hipError_t launch_render_f32(const CamDev<float>& cam, const SceneDev& scene, co
         boxes ? launch(render_f32_kernel<kScanScalar, true>) : launch(render_f32_kernel<kScanScalar, false>);
     return hipGetLastError();
 }
+
+#ifdef DRAY_SECTION_CLOCKS
+// Diagnostic builds only: reads and clears the section clocks.
+extern "C" int dray_debug_section_clocks(unsigned long long* out) {
+    unsigned long long zero[16] = {};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(dray_section_clocks), sizeof zero) != hipSuccess) return -1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(dray_section_clocks), zero, sizeof zero) == hipSuccess ? 0 : -1;
+}
+#endif
 
 #ifdef DRAY_SECTION_COUNTERS
 // Diagnostic builds only: reads and clears the section counters.
