@@ -342,10 +342,13 @@ __device__ __forceinline__ bool walk_begin(ConstPtr<GridDev> gp, const PathRay& 
     w.best = kNoHit;
     ConstPtr<V4> loose_geom = as_constant((const V4*)g.loose_geom);
     ConstPtr<int32_t> loose_index = as_constant(g.loose_index);
-    for (int32_t k = 0; k < g.n_loose_padded; k += 4) { // wave-uniform; four rows and their list positions per scalar load
+    const int32_t n_loose = g.n_loose; // wave-uniform; rows and list positions arrive through scalar loads, in fours
+    int32_t k = 0;
+    for (; k + 4 <= n_loose; k += 4) {
 #pragma unroll
         for (int32_t u = 0; u < 4; ++u) walk_test(w, loose_geom[k + u], loose_index[k + u], ray);
     }
+    for (; k < n_loose; ++k) walk_test(w, loose_geom[k], loose_index[k], ray); // (padding rows are never read)
     if (g.n[0] == 0) return false;
     const float o[3] = {ray.o.x, ray.o.y, ray.o.z}, d[3] = {ray.d.x, ray.d.y, ray.d.z};
     float t_in = 0.f, t_out = INFINITY, bmax = 0.f;
