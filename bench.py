@@ -141,8 +141,8 @@ def executed_roofline(cnt, current, cfile, kernel_name, k_s, peak, f64=False):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", type=int, default=3, choices=sorted(CONFIGS), help="BASELINE.json configuration (3 = headline)")
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--spp", type=int, default=0)
@@ -213,14 +213,27 @@ def main():
     segs = samples = 0
     kernel_ms = resolve_ms = 0.0
     image = None
-    for _ in range(args.steps):
-        image, st = renderer.step(time_gather=True)
+    # The steps are enqueued back to back (a step's statistics are collected a few steps later, when it has long ended), so
+    # that a step's trace kernel can begin while the previous step's is running out and its gather is on the way.
+    pending = []
+
+    def collect(ticket):
+        nonlocal segs, samples, kernel_ms, resolve_ms
+        st = ticket.stats() if hasattr(ticket, "stats") else ticket
         segs += st.segments
         samples += st.samples
         kernel_ms += st.kernel_ms
         resolve_ms += st.resolve_ms
+
+    for _ in range(args.steps):
+        image, ticket = renderer.step(time_gather=True, stats_later=True)
+        pending.append(ticket)
+        if len(pending) > 6:
+            collect(pending.pop(0))
     sync()
     elapsed = time.perf_counter() - t0
+    for ticket in pending:
+        collect(ticket)
     gather_ms = renderer.gather_ms() / max(args.steps, 1)
     my_kernel_ms = kernel_ms / max(args.steps, 1)
 

@@ -135,7 +135,7 @@ EXPORTS = (
     "dray_camera_initialize", "dray_render", "dray_render_multi", "dray_scene_create", "dray_scene_destroy", "dray_render_device",
     "dray_scene_final", "dray_scene_recipe", "dray_scene_three_spheres", "dray_write_ppm", "dray_camera_rays",
     "dray_path_step", "dray_camera_rays_device", "dray_path_step_device", "dray_grid_inspect",
-    "dray_render_device_noalloc", "dray_release_cache", "dray_context_create", "dray_context_destroy",
+    "dray_render_device_noalloc", "dray_render_device_async", "dray_scene_collect", "dray_release_cache", "dray_context_create", "dray_context_destroy",
     "dray_context_set_scene", "dray_context_render", "dray_context_pin", "dray_context_unpin", "dray_context_host_alloc",
 )
 
@@ -186,6 +186,9 @@ def lib():
     L.dray_render_device.argtypes = [P(CameraPOD), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, P(Opts),
                                      C.c_void_p, P(Stats)]
     L.dray_render_device_noalloc.argtypes = L.dray_render_device.argtypes
+    L.dray_render_device_async.argtypes = [P(CameraPOD), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, P(Opts),
+                                           C.c_void_p, P(C.c_uint64)]
+    L.dray_scene_collect.argtypes = [C.c_void_p, C.c_uint64, P(Stats)]
     L.dray_release_cache.restype = None
     L.dray_release_cache.argtypes = []
     L.dray_context_create.argtypes = [C.c_void_p, C.c_int32, P(C.c_void_p)]

@@ -21,21 +21,47 @@
 
 using namespace dray;
 
+// What one call on a scene needs for itself: counters (the trace kernels' work-queue head among them), the three
+// events its timings come from, and what its statistics cannot be read off the device.  A scene keeps the last
+// kCallSlots calls' slots, so that a caller may enqueue several calls and ask for their statistics afterwards.
+constexpr int kCallSlots = 16;
+struct CallSlot {
+    DeviceCounters* d_counters = nullptr; // this slot's counters (or, for the allocation-free call, the static workspace's)
+    DeviceCounters* own_counters = nullptr;
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr}; // trace begins, trace ends, results are in the caller's buffers
+    uint64_t ticket = 0;                            // number of the call that holds the slot (1, 2, ...); 0: none yet
+    dray_stats base{};                              // the fields known on the host
+    bool samples_from_frame = false;                // f32 mode without depth: no kernel counts the samples
+    std::chrono::steady_clock::time_point t_begin;
+};
+
+// Where an f32 trace kernel runs: fixed-point colour sums of its own and a stream of its own.  A scene has two and
+// gives them to its calls in turn, so that the trace kernel of a call -- it reads nothing but the scene -- may start
+// while the previous call's kernel is still running out, instead of after its last wave.
+struct TraceSpace {
+    unsigned long long* d_accum = nullptr;
+    size_t accum_capacity = 0;    // in u64 words
+    hipStream_t side = nullptr;
+    hipEvent_t free_after = nullptr; // recorded when the call that last used the space has read its sums
+};
+
 struct dray_scene {
     int32_t device = 0;
     SceneDev dev;
-    DeviceCounters* d_counters = nullptr;
-    unsigned long long* d_accum = nullptr; // fixed-point colour sums of the f32 kernel
-    size_t accum_capacity = 0;             // in u64 words
+    DeviceCounters* d_counter_block = nullptr; // kCallSlots counters, 256 bytes apart
+    CallSlot slots[kCallSlots];
+    uint64_t calls = 0;                        // calls that have taken a slot
+    TraceSpace space[2];
+    int next_space = 0;
+    hipStream_t stats_stream = nullptr;        // copies of the counters to the host
     void* d_rings = nullptr;               // the f64 stream kernel's rings of finished samples (one per resident wave)
     size_t rings_bytes = 0;
-    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
-    // The counters, the sums and the events are one set per scene, so a scene serves one call at a time: host
-    // threads take `mu` for the length of a call, and a call enqueued on another stream than the one before it
-    // first makes its stream wait for that call's last event.
+    // Calls on one scene take turns on the host (`mu`, for the length of the enqueueing), and a call enqueued on
+    // another stream than the one before it first makes its stream wait for that call's last event: the calls
+    // of a scene reach the caller's buffers in the order they were made.
     std::mutex mu;
     hipStream_t last_stream = nullptr;
-    bool has_last = false;
+    hipEvent_t last_done = nullptr;
 };
 
 // Workspace of the allocation-free entry point (dray_render_device_noalloc): the f32 kernel's fixed-point sums
@@ -175,9 +201,15 @@ void scene_free(dray_scene* s) {
     (void)hipFree(d.box64); (void)hipFree(d.box_index);
     (void)hipFree(d.loose_geom); (void)hipFree(d.loose_index); (void)hipFree(d.wide_geom64);
     (void)hipFree(d.entry_geom64); (void)hipFree(d.entry_index); (void)hipFree(d.always_geom64); (void)hipFree(d.always_index);
-    (void)hipFree(s->d_counters); (void)hipFree(s->d_accum); (void)hipFree(s->d_rings);
-    for (auto& e : s->ev)
-        if (e) (void)hipEventDestroy(e);
+    (void)hipFree(s->d_counter_block); (void)hipFree(s->d_rings);
+    for (TraceSpace& t : s->space) {
+        (void)hipFree(t.d_accum);
+        if (t.side) (void)hipStreamDestroy(t.side);
+    }
+    if (s->stats_stream) (void)hipStreamDestroy(s->stats_stream);
+    for (CallSlot& c : s->slots)
+        for (auto& e : c.ev)
+            if (e) (void)hipEventDestroy(e);
     delete s;
 }
 
@@ -592,9 +624,17 @@ int scene_create_impl(const dray_sphere* sp, size_t n, int32_t device, dray_scen
             d.f32.bound[3] = (float)(1.01 * reach + 1e-6 * (std::fabs(d.f32.bound[0]) + std::fabs(d.f32.bound[1]) + std::fabs(d.f32.bound[2])) + 1e-30);
         }
     }
-    hipError_t e = hipMalloc((void**)&s->d_counters, sizeof(DeviceCounters));
-    for (auto& ev : s->ev)
-        if (e == hipSuccess) e = hipEventCreate(&ev);
+    constexpr size_t kCounterStride = 256; // counters of calls in flight at once do not share a cache line
+    static_assert(sizeof(DeviceCounters) <= kCounterStride, "counters outgrew their stride");
+    hipError_t e = hipMalloc((void**)&s->d_counter_block, kCallSlots * kCounterStride);
+    for (int q = 0; q < kCallSlots && e == hipSuccess; ++q) {
+        s->slots[q].own_counters = (DeviceCounters*)((char*)s->d_counter_block + q * kCounterStride);
+        for (auto& ev : s->slots[q].ev)
+            if (e == hipSuccess) e = hipEventCreate(&ev);
+    }
+    for (TraceSpace& t : s->space)
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&t.side, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->stats_stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         scene_free(s);
         return hip_fail(e, "scene workspace");
@@ -628,10 +668,55 @@ unsigned long long* noalloc_workspace(int device) {
     return g_noalloc_ptr[device];
 }
 
+// Takes the scene's next call slot (the scene's lock is held).  The slot's previous holder, kCallSlots calls ago, has
+// to be over before its counters and events serve again.
+int take_slot(dray_scene* scene, CallSlot** out) {
+    const uint64_t ticket = ++scene->calls;
+    CallSlot* slot = &scene->slots[ticket % kCallSlots];
+    if (slot->ticket) HIP_TRY(hipEventSynchronize(slot->ev[2]));
+    slot->ticket = ticket;
+    slot->d_counters = slot->own_counters;
+    slot->base = dray_stats{};
+    slot->samples_from_frame = false;
+    slot->t_begin = std::chrono::steady_clock::now();
+    *out = slot;
+    return DRAY_OK;
+}
+
+// Waits for the call that holds `ticket` and fills in its statistics.
+int collect_call(dray_scene* scene, uint64_t ticket, dray_stats* stats) {
+    if (!scene || !stats || ticket == 0) return DRAY_ERR_INVALID_ARG;
+    DeviceGuard g(scene->device);
+    if (g.err != hipSuccess) return hip_fail(g.err, "hipSetDevice");
+    std::lock_guard<std::mutex> lock(scene->mu);
+    CallSlot* slot = &scene->slots[ticket % kCallSlots];
+    if (slot->ticket != ticket) {
+        snprintf(g_detail, sizeof g_detail, "call %llu of this scene is not among its last %d", (unsigned long long)ticket, kCallSlots);
+        return DRAY_ERR_INVALID_ARG;
+    }
+    HIP_TRY(hipEventSynchronize(slot->ev[2]));
+    // (on a stream of the scene's own: a copy on the default stream would wait for everything enqueued there since,
+    // the renders that came after this one among it)
+    DeviceCounters hc{};
+    HIP_TRY(hipMemcpyAsync(&hc, slot->d_counters, sizeof hc, hipMemcpyDeviceToHost, scene->stats_stream));
+    HIP_TRY(hipStreamSynchronize(scene->stats_stream));
+    float k_ms = 0.f, r_ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&k_ms, slot->ev[0], slot->ev[1]));
+    HIP_TRY(hipEventElapsedTime(&r_ms, slot->ev[1], slot->ev[2]));
+    *stats = slot->base;
+    stats->segments = hc.segments;
+    stats->walk_steps = hc.walk_steps;
+    if (!slot->samples_from_frame) stats->samples = hc.samples;
+    stats->kernel_ms = k_ms;
+    stats->resolve_ms = r_ms;
+    stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - slot->t_begin).count();
+    return DRAY_OK;
+}
+
 // One render on one scene, in the steps its callers need apart: check the arguments (prepare), start the trace
 // kernel, which reads only the scene (begin), then -- once the running sums it adds to are in place -- the kernel that
 // reads and writes the caller's buffers (finish), and, after the work is done, the statistics (collect).  The job holds
-// the scene's lock from prepare to finish: a scene serves one call at a time.
+// the scene's lock from begin to finish.
 struct RenderJob {
     const dray_camera* cam = nullptr;
     dray_scene* scene = nullptr;
@@ -643,6 +728,10 @@ struct RenderJob {
     hipStream_t stream = nullptr;
     DeviceCounters* d_counters = nullptr;
     unsigned long long* d_accum = nullptr;
+    CallSlot* slot = nullptr;
+    TraceSpace* space = nullptr;
+    uint64_t ticket = 0;
+    dray_stats base{};
     F32Plan plan{};
     std::unique_lock<std::mutex> lock;
     std::chrono::steady_clock::time_point t_begin;
@@ -669,29 +758,35 @@ struct RenderJob {
         if (buf_len < need) return DRAY_ERR_BUFFER_TOO_SMALL;
         const bool exact_product = opts.mode != DRAY_MODE_F32 && !(opts.flags & DRAY_FLAG_ITERATIVE_PRODUCT);
         if (exact_product && cam->max_depth > kExactMaxDepth) return DRAY_ERR_UNSUPPORTED;
-        if (stats) {
-            std::memset(stats, 0, sizeof *stats);
-            stats->image_height = H;
-            stats->rows_rendered = part.n_rows;
-            stats->n_spheres = scene->dev.n;
-            stats->n_wide_spheres = opts.mode == DRAY_MODE_F32 ? scene->dev.n_wide : 0;
-        }
+        base = dray_stats{};
+        base.image_height = H;
+        base.rows_rendered = part.n_rows;
+        base.n_spheres = scene->dev.n;
+        base.n_wide_spheres = opts.mode == DRAY_MODE_F32 ? scene->dev.n_wide : 0;
+        if (stats) *stats = base;
         empty = cam->samples_per_pixel <= 0 || part.n_rows == 0;
         stream = (hipStream_t)stream_v;
         return DRAY_OK;
     }
 
-    // Clears the workspace and, in the f32 mode, enqueues the trace kernel.
+    // Takes a call slot, clears the workspace and, in the f32 mode, enqueues the trace kernel.
     int begin() {
         DeviceGuard g(scene->device);
         if (g.err != hipSuccess) return hip_fail(g.err, "hipSetDevice");
-        lock = std::unique_lock<std::mutex>(scene->mu); // one call at a time per scene (see dray_scene)
-        if (scene->has_last && scene->last_stream != stream) HIP_TRY(hipStreamWaitEvent(stream, scene->ev[2], 0));
+        lock = std::unique_lock<std::mutex>(scene->mu); // calls take turns (see dray_scene)
+        if (scene->last_done && scene->last_stream != stream) HIP_TRY(hipStreamWaitEvent(stream, scene->last_done, 0));
         scene->last_stream = stream;
+        int rc = take_slot(scene, &slot);
+        if (rc) return rc;
+        ticket = slot->ticket;
+        slot->base = base;
+        slot->t_begin = t_begin;
+        slot->samples_from_frame = opts.mode == DRAY_MODE_F32 && cam->max_depth <= 0;
+        if (slot->samples_from_frame)
+            slot->base.samples = (uint64_t)part.n_rows * (uint64_t)W * (uint64_t)cam->samples_per_pixel;
 
-        // the counters and the f32 kernel's sums: the scene's own buffers (grown when a frame needs more), or the
+        // the counters and the f32 kernel's sums: the scene's own (the sums grown when a frame needs more), or the
         // library's static array for the entry point that may not allocate
-        d_counters = scene->d_counters;
         if (noalloc) {
             if ((size_t)part.n_rows * (size_t)W > kNoAllocMaxPixels) {
                 snprintf(g_detail, sizeof g_detail, "%d rows x %d pixels exceed the %zu pixels of the allocation-free workspace",
@@ -700,34 +795,45 @@ struct RenderJob {
             }
             unsigned long long* ws = noalloc_workspace(scene->device);
             if (!ws) return DRAY_ERR_HIP;
-            d_counters = (DeviceCounters*)ws;
+            slot->d_counters = (DeviceCounters*)ws;
             d_accum = ws + kNoAllocCounterWords;
         }
+        d_counters = slot->d_counters;
         static_assert(sizeof(DeviceCounters) <= kNoAllocCounterWords * sizeof(unsigned long long), "counters outgrew their slot");
 
-        HIP_TRY(hipMemsetAsync(d_counters, 0, sizeof(DeviceCounters), stream));
-        if (opts.mode == DRAY_MODE_F32) {
-            const CamDev<float> c = make_cam<float>(*cam, dv);
-            plan = plan_render_f32(c, part, opts.pixels_per_pool, opts.variant, scene->dev, scene->device);
-            plan.no_refill = (opts.flags & DRAY_FLAG_NO_REFILL) ? 1 : 0;
-            if (opts.variant == DRAY_SCAN_HYBRID && plan.scan != DRAY_SCAN_HYBRID) return DRAY_ERR_UNSUPPORTED; // table beyond the LDS staging limit
-            if (!noalloc) {
-                if (plan.accum_words > scene->accum_capacity) {
-                    if (scene->d_accum) HIP_TRY(hipFree(scene->d_accum)); // waits for the device: no earlier call still reads it
-                    scene->d_accum = nullptr;
-                    scene->accum_capacity = 0;
-                    HIP_TRY(hipMalloc((void**)&scene->d_accum, plan.accum_words * sizeof(unsigned long long)));
-                    scene->accum_capacity = plan.accum_words;
-                }
-                d_accum = scene->d_accum;
-            }
-            HIP_TRY(hipMemsetAsync(d_accum, 0, plan.accum_words * sizeof(unsigned long long), stream));
-            HIP_TRY(hipEventRecord(scene->ev[0], stream));
-            const RngKey key = {(uint32_t)opts.seed, (uint32_t)(opts.seed >> 32), opts.sample_offset};
-            if (cam->max_depth > 0) // camera.rs:265: with no depth every sample is black and no ray is traced
-                HIP_TRY(launch_render_f32(c, scene->dev, part, key, plan, d_accum, d_counters, stream));
-            HIP_TRY(hipEventRecord(scene->ev[1], stream));
+        if (opts.mode != DRAY_MODE_F32) {
+            HIP_TRY(hipMemsetAsync(d_counters, 0, sizeof(DeviceCounters), stream));
+            return DRAY_OK;
         }
+        const CamDev<float> c = make_cam<float>(*cam, dv);
+        plan = plan_render_f32(c, part, opts.pixels_per_pool, opts.variant, scene->dev, scene->device);
+        plan.no_refill = (opts.flags & DRAY_FLAG_NO_REFILL) ? 1 : 0;
+        if (opts.variant == DRAY_SCAN_HYBRID && plan.scan != DRAY_SCAN_HYBRID) return DRAY_ERR_UNSUPPORTED; // table beyond the LDS staging limit
+        // The trace kernel runs on the stream of one of the scene's two trace spaces (the allocation-free call: on
+        // the caller's stream, over the static workspace); the caller's stream picks up when it has ended.
+        hipStream_t trace_stream = stream;
+        if (!noalloc) {
+            space = &scene->space[scene->next_space];
+            scene->next_space ^= 1;
+            if (plan.accum_words > space->accum_capacity) {
+                if (space->d_accum) HIP_TRY(hipFree(space->d_accum)); // waits for the device: no earlier call still reads it
+                space->d_accum = nullptr;
+                space->accum_capacity = 0;
+                HIP_TRY(hipMalloc((void**)&space->d_accum, plan.accum_words * sizeof(unsigned long long)));
+                space->accum_capacity = plan.accum_words;
+            }
+            d_accum = space->d_accum;
+            trace_stream = space->side;
+            if (space->free_after) HIP_TRY(hipStreamWaitEvent(trace_stream, space->free_after, 0)); // its last user has read the sums
+        }
+        HIP_TRY(hipMemsetAsync(d_counters, 0, sizeof(DeviceCounters), trace_stream));
+        HIP_TRY(hipMemsetAsync(d_accum, 0, plan.accum_words * sizeof(unsigned long long), trace_stream));
+        HIP_TRY(hipEventRecord(slot->ev[0], trace_stream));
+        const RngKey key = {(uint32_t)opts.seed, (uint32_t)(opts.seed >> 32), opts.sample_offset};
+        if (cam->max_depth > 0) // camera.rs:265: with no depth every sample is black and no ray is traced
+            HIP_TRY(launch_render_f32(c, scene->dev, part, key, plan, d_accum, d_counters, trace_stream));
+        HIP_TRY(hipEventRecord(slot->ev[1], trace_stream));
+        if (trace_stream != stream) HIP_TRY(hipStreamWaitEvent(stream, slot->ev[1], 0));
         return DRAY_OK;
     }
 
@@ -740,9 +846,10 @@ struct RenderJob {
         if (inputs_ready) HIP_TRY(hipStreamWaitEvent(stream, inputs_ready, 0));
         if (opts.mode == DRAY_MODE_F32) {
             HIP_TRY(launch_resolve_f32(make_cam<float>(*cam, dv), part, d_accum, d_color, d_raw, d_count, stream));
-            HIP_TRY(hipEventRecord(scene->ev[2], stream));
+            HIP_TRY(hipEventRecord(slot->ev[2], stream));
+            if (space) space->free_after = slot->ev[2];
         } else {
-            HIP_TRY(hipEventRecord(scene->ev[0], stream));
+            HIP_TRY(hipEventRecord(slot->ev[0], stream));
             if (opts.mode == DRAY_MODE_F64) {
                 const CamDev<double> c = make_cam<double>(*cam, dv);
                 // Three organisations, one result: every sphere of the list per ray, one thread per pixel (scalar); the
@@ -770,10 +877,10 @@ struct RenderJob {
             else
                 HIP_TRY(launch_render_ref_f32(make_cam<float>(*cam, dv), scene->dev, part, key, opts.flags, d_color, d_raw,
                                               d_count, d_counters, stream));
-            HIP_TRY(hipEventRecord(scene->ev[1], stream));
-            HIP_TRY(hipEventRecord(scene->ev[2], stream));
+            HIP_TRY(hipEventRecord(slot->ev[1], stream));
+            HIP_TRY(hipEventRecord(slot->ev[2], stream));
         }
-        scene->has_last = true;
+        scene->last_done = slot->ev[2];
         lock.unlock();
         return DRAY_OK;
     }
@@ -782,31 +889,14 @@ struct RenderJob {
         if (lock.owns_lock()) lock.unlock();
     }
 
-    // Waits for the job and fills in what the device counted.  Call before the scene takes its next job.
-    int collect(dray_stats* stats) {
-        DeviceGuard g(scene->device);
-        if (g.err != hipSuccess) return hip_fail(g.err, "hipSetDevice");
-        HIP_TRY(hipEventSynchronize(scene->ev[2]));
-        DeviceCounters hc{};
-        HIP_TRY(hipMemcpy(&hc, d_counters, sizeof hc, hipMemcpyDeviceToHost));
-        float k_ms = 0.f, r_ms = 0.f;
-        HIP_TRY(hipEventElapsedTime(&k_ms, scene->ev[0], scene->ev[1]));
-        HIP_TRY(hipEventElapsedTime(&r_ms, scene->ev[1], scene->ev[2]));
-        stats->segments = hc.segments;
-        stats->walk_steps = hc.walk_steps;
-        stats->samples = (opts.mode == DRAY_MODE_F32 && cam->max_depth <= 0)
-                             ? (uint64_t)part.n_rows * (uint64_t)W * (uint64_t)cam->samples_per_pixel
-                             : hc.samples;
-        stats->kernel_ms = k_ms;
-        stats->resolve_ms = r_ms;
-        stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
-        return DRAY_OK;
-    }
+    // Waits for the job and fills in what the device counted.
+    int collect(dray_stats* stats) { return collect_call(scene, ticket, stats); }
 };
 
 int render_device_impl(const dray_camera* cam, dray_scene* scene, uint32_t* d_color, double* d_raw, int32_t* d_count,
                        size_t buf_len, const dray_opts* opts_in, void* stream_v, dray_stats* stats,
-                       bool noalloc = false) {
+                       bool noalloc = false, uint64_t* ticket = nullptr) {
+    if (ticket) *ticket = 0;
     RenderJob job;
     int rc = job.prepare(cam, scene, d_color != nullptr, buf_len, opts_in, stream_v, noalloc, stats);
     if (rc || job.empty) return rc;
@@ -814,6 +904,7 @@ int render_device_impl(const dray_camera* cam, dray_scene* scene, uint32_t* d_co
         job.abandon();
         return rc;
     }
+    if (ticket) *ticket = job.ticket;
     return stats ? job.collect(stats) : DRAY_OK;
 }
 
@@ -1313,7 +1404,7 @@ int camera_rays_device_impl(const dray_camera* cam, const dray_pixel_index* d_px
 }
 
 int path_step_device_impl(dray_scene* scene, int32_t image_width, dray_path_entry* d_entries, size_t n,
-                          const dray_opts* opts_in, void* stream_v, bool count) {
+                          const dray_opts* opts_in, void* stream_v, bool count, uint64_t* ticket = nullptr) {
     if (!scene || image_width < 1 || (n && !d_entries)) return DRAY_ERR_INVALID_ARG;
     dray_opts opts;
     if (opts_in) opts = *opts_in; else dray_opts_default(&opts);
@@ -1324,15 +1415,20 @@ int path_step_device_impl(dray_scene* scene, int32_t image_width, dray_path_entr
     hipStream_t stream = (hipStream_t)stream_v;
     if (count) { // only the counting form touches the scene's workspace; the plain form reads the sphere tables alone
         std::lock_guard<std::mutex> lock(scene->mu);
-        if (scene->has_last && scene->last_stream != stream) HIP_TRY(hipStreamWaitEvent(stream, scene->ev[2], 0));
+        if (scene->last_done && scene->last_stream != stream) HIP_TRY(hipStreamWaitEvent(stream, scene->last_done, 0));
         scene->last_stream = stream;
-        HIP_TRY(hipMemsetAsync(scene->d_counters, 0, sizeof(DeviceCounters), stream));
-        HIP_TRY(hipEventRecord(scene->ev[0], stream));
+        CallSlot* slot = nullptr;
+        const int rc = take_slot(scene, &slot);
+        if (rc) return rc;
+        slot->base.n_spheres = scene->dev.n;
+        HIP_TRY(hipMemsetAsync(slot->d_counters, 0, sizeof(DeviceCounters), stream));
+        HIP_TRY(hipEventRecord(slot->ev[0], stream));
         HIP_TRY(launch_path_step(scene->dev, key, image_width, opts.variant != DRAY_SCAN_SCALAR, d_entries, n,
-                                 scene->d_counters, stream));
-        HIP_TRY(hipEventRecord(scene->ev[1], stream));
-        HIP_TRY(hipEventRecord(scene->ev[2], stream));
-        scene->has_last = true;
+                                 slot->d_counters, stream));
+        HIP_TRY(hipEventRecord(slot->ev[1], stream));
+        HIP_TRY(hipEventRecord(slot->ev[2], stream));
+        scene->last_done = slot->ev[2];
+        if (ticket) *ticket = slot->ticket;
         return DRAY_OK;
     }
     HIP_TRY(launch_path_step(scene->dev, key, image_width, opts.variant != DRAY_SCAN_SCALAR, d_entries, n, nullptr, stream));
@@ -1379,17 +1475,13 @@ int path_step_host_impl(dray_scene* scene, int32_t image_width, dray_path_entry*
     DevBuf<dray_path_entry> d_e;
     HIP_TRY(d_e.alloc(n));
     HIP_TRY(hipMemcpy(d_e.p, entries, n * sizeof *entries, hipMemcpyHostToDevice));
-    const int rc = path_step_device_impl(scene, image_width, d_e.p, n, opts_in, nullptr, true);
+    uint64_t ticket = 0;
+    const int rc = path_step_device_impl(scene, image_width, d_e.p, n, opts_in, nullptr, true, &ticket);
     if (rc) return rc;
     HIP_TRY(hipMemcpy(entries, d_e.p, n * sizeof *entries, hipMemcpyDeviceToHost));
     if (stats) {
-        DeviceCounters hc;
-        HIP_TRY(hipMemcpy(&hc, scene->d_counters, sizeof hc, hipMemcpyDeviceToHost));
-        stats->segments = hc.segments;
-        stats->n_spheres = scene->dev.n;
-        float k_ms = 0.f; // the copies above have waited for the kernel
-        HIP_TRY(hipEventElapsedTime(&k_ms, scene->ev[0], scene->ev[1]));
-        stats->kernel_ms = k_ms;
+        const int rc2 = collect_call(scene, ticket, stats);
+        if (rc2) return rc2;
         stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     }
     return DRAY_OK;
@@ -1613,6 +1705,23 @@ int dray_render_device(const dray_camera* cam, dray_scene* scene, uint32_t* d_co
                        size_t buf_len, const dray_opts* opts, void* stream, dray_stats* stats) {
     try {
         return render_device_impl(cam, scene, d_color, d_raw, d_count, buf_len, opts, stream, stats);
+    } catch (...) {
+        return DRAY_ERR_INTERNAL;
+    }
+}
+
+int dray_render_device_async(const dray_camera* cam, dray_scene* scene, uint32_t* d_color, double* d_raw, int32_t* d_count,
+                             size_t buf_len, const dray_opts* opts, void* stream, uint64_t* ticket) {
+    try {
+        return render_device_impl(cam, scene, d_color, d_raw, d_count, buf_len, opts, stream, nullptr, false, ticket);
+    } catch (...) {
+        return DRAY_ERR_INTERNAL;
+    }
+}
+
+int dray_scene_collect(dray_scene* scene, uint64_t ticket, dray_stats* stats) {
+    try {
+        return collect_call(scene, ticket, stats);
     } catch (...) {
         return DRAY_ERR_INTERNAL;
     }

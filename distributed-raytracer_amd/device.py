@@ -67,10 +67,24 @@ def alloc_buffers(cam: Camera, device, rows=None, with_raw=True):
     return color, raw, count
 
 
+class Ticket:
+    """A render that has been enqueued and not looked at yet (dray_render_device_async); ``stats()`` waits for it."""
+
+    def __init__(self, scene, number):
+        self.scene, self.number = scene, int(number)
+
+    def stats(self):
+        st = _ffi.Stats()
+        if self.number:
+            _ffi.check(_ffi.lib().dray_scene_collect(self.scene.handle, C.c_uint64(self.number), C.byref(st)))
+        return st
+
+
 def render_device(cam: Camera, scene: DeviceScene, color, raw=None, count=None, stream=None, want_stats=True,
                   noalloc=False, **opt_overrides):
-    """Camera::render with device buffers.  Returns dray_stats (or None when want_stats is False: then the
-    call only enqueues work on ``stream``).  ``noalloc`` takes the entry point that never allocates device memory
+    """Camera::render with device buffers.  Returns dray_stats; with ``want_stats=False`` None (the call only enqueues
+    work on ``stream``); with ``want_stats="later"`` a Ticket whose ``stats()`` waits for the call -- so that several
+    renders can be enqueued back to back.  ``noalloc`` takes the entry point that never allocates device memory
     (dray_render_device_noalloc: the library's static workspace, frames of at most NOALLOC_MAX_PIXELS pixels)."""
     import torch
     pc, nc = _ptr(color, torch.int32, "color")
@@ -88,6 +102,11 @@ def render_device(cam: Camera, scene: DeviceScene, color, raw=None, count=None, 
     pod = cam.pod()
     opts = cam.opts(**opt_overrides)
     opts.device = scene.device
+    if want_stats == "later" and not noalloc:
+        number = C.c_uint64(0)
+        _ffi.check(_ffi.lib().dray_render_device_async(C.byref(pod), scene.handle, pc, pr, pn, buf_len, C.byref(opts),
+                                                       C.c_void_p(stream.cuda_stream), C.byref(number)))
+        return Ticket(scene, number.value)
     st = _ffi.Stats() if want_stats else None
     call = _ffi.lib().dray_render_device_noalloc if noalloc else _ffi.lib().dray_render_device
     rc = call(C.byref(pod), scene.handle, pc, pr, pn, buf_len, C.byref(opts), C.c_void_p(stream.cuda_stream),

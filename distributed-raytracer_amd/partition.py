@@ -103,11 +103,17 @@ class DistributedRenderer:
         self.samples_done = 0
         self._gather_events = []
 
-    def step(self, gather=True, time_gather=False):
+    def step(self, gather=True, time_gather=False, stats_later=False):
         """One pass of the camera's samples_per_pixel over this rank's rows, then the gather.  With ``time_gather`` the
-        gather is bracketed by two events on the current stream (read later through gather_ms, without a wait here)."""
-        stats = self.render_rows(self.cam, self.row_begin, self.row_step, self.color, self.raw, self.count,
-                                 self.samples_done)
+        gather is bracketed by two events on the current stream (read later through gather_ms, without a wait here).
+        With ``stats_later`` the render is only enqueued and what comes back in the statistics' place has a
+        ``stats()`` that waits for it (a backend without that simply returns the statistics)."""
+        if stats_later:
+            stats = self.render_rows(self.cam, self.row_begin, self.row_step, self.color, self.raw, self.count,
+                                     self.samples_done, want_stats="later")
+        else:
+            stats = self.render_rows(self.cam, self.row_begin, self.row_step, self.color, self.raw, self.count,
+                                     self.samples_done)
         self.samples_done += self.cam.samples_per_pixel
         timed = gather and time_gather and getattr(self.color, "is_cuda", False)
         if timed:
@@ -143,10 +149,10 @@ def gpu_render_rows(scene, **opt_overrides):
     from . import _ffi
     from .device import render_device
 
-    def fn(cam, row_begin, row_step, color, raw, count, sample_offset):
+    def fn(cam, row_begin, row_step, color, raw, count, sample_offset, want_stats=True):
         flags = cam.flags | _ffi.FLAG_COMPACT_ROWS
         return render_device(cam, scene, color, raw, count, row_begin=row_begin, row_step=row_step, flags=flags,
-                             sample_offset=sample_offset, **opt_overrides)
+                             sample_offset=sample_offset, want_stats=want_stats, **opt_overrides)
 
     return fn
 

@@ -250,11 +250,22 @@ void dray_scene_destroy(dray_scene* scene);
 /* Same contract as dray_render but color/raw/count are device pointers on the scene's device
  * and the work is enqueued on `stream` (a hipStream_t, NULL = default stream).  With stats == NULL
  * the call returns once the work is enqueued; with stats it waits for completion and fills them.
- * A dray_scene owns one workspace (counters, colour sums, events), so it serves one call at a time: calls from
- * several host threads take turns, and a call on another stream than the scene's previous call first makes its
- * stream wait for that call to finish on the GPU.  For renders that should overlap, create one scene per stream. */
+ * The calls on one scene take turns: calls from several host threads are enqueued one after the other, and a call
+ * on another stream than the scene's previous call first makes its stream wait for that call to finish on the GPU, so
+ * the calls of a scene reach the caller's buffers in the order they were made.  (In DRAY_MODE_F32 the trace kernel of
+ * a call, which reads the scene alone, runs on a stream of the scene's own and may begin while the previous call's
+ * kernel is still running out; `stream` waits for it before anything touches the buffers.)  For renders that should
+ * run side by side, create one scene per stream. */
 int dray_render_device(const dray_camera* cam, dray_scene* scene, uint32_t* d_color, double* d_raw, int32_t* d_count,
                        size_t buf_len, const dray_opts* opts, void* stream, dray_stats* stats);
+
+/* The same call for a caller that enqueues several renders before it looks at any of them (the passes of a progressive
+ * render, the steps of a benchmark): returns once the work is enqueued and hands out a ticket (0 when there was
+ * nothing to render); dray_scene_collect waits for that call and fills in its statistics.  A scene remembers its last
+ * 16 calls: an older ticket is DRAY_ERR_INVALID_ARG.  No counterpart in the reference, whose render call is synchronous. */
+int dray_render_device_async(const dray_camera* cam, dray_scene* scene, uint32_t* d_color, double* d_raw, int32_t* d_count,
+                             size_t buf_len, const dray_opts* opts, void* stream, uint64_t* ticket);
+int dray_scene_collect(dray_scene* scene, uint64_t ticket, dray_stats* stats);
 
 /* dray_render_device for callers that cannot allocate device memory: code under HIP graph capture, tight serving
  * loops, harnesses that forbid hipMalloc.  It has no counterpart in the reference.  Same arguments, same results

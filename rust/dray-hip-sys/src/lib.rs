@@ -253,6 +253,18 @@ extern "C" {
         stream: *mut c_void,
         stats: *mut dray_stats,
     ) -> c_int;
+    pub fn dray_render_device_async(
+        cam: *const dray_camera,
+        scene: *mut dray_scene,
+        d_color: *mut u32,
+        d_raw: *mut f64,
+        d_count: *mut i32,
+        buf_len: usize,
+        opts: *const dray_opts,
+        stream: *mut c_void,
+        ticket: *mut u64,
+    ) -> c_int;
+    pub fn dray_scene_collect(scene: *mut dray_scene, ticket: u64, stats: *mut dray_stats) -> c_int;
     pub fn dray_render_device_noalloc(
         cam: *const dray_camera,
         scene: *mut dray_scene,

@@ -16,7 +16,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ranks", type=int, nargs="+", default=[1, 2, 4, 8])
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=12)
     args = ap.parse_args()
     import torch
     import dray_amd as d
@@ -29,20 +29,25 @@ def main():
         cam.mode = d.MODE_F32
         r = partition.DistributedRenderer(cam, partition.gpu_render_rows(scene), partition.gpu_alloc(0), rank=0,
                                           world_size=G)
-        r.step()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        k = 0.0
-        segs = 0
-        for _ in range(args.steps):
-            _, st = r.step()
-            k += st.kernel_ms
-            segs += st.segments
-        torch.cuda.synchronize()
-        wall = (time.perf_counter() - t0) * 1e3 / args.steps
-        print(json.dumps({"ranks": G, "wall_ms_per_step": round(wall, 3), "kernel_ms": round(k / args.steps, 3),
-                          "overhead_ms": round(wall - k / args.steps, 3),
-                          "mrays_s_if_all_ranks_alike": round(G * segs / args.steps / wall / 1e3, 1)}))
+        for pipelined in (False, True):
+            r.step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            k = 0.0
+            segs = 0
+            tickets = []
+            for _ in range(args.steps):
+                _, st = r.step(stats_later=pipelined)   # pipelined: steps enqueued back to back, looked at afterwards
+                tickets.append(st)
+            torch.cuda.synchronize()
+            wall = (time.perf_counter() - t0) * 1e3 / args.steps
+            for st in tickets:
+                st = st.stats() if pipelined else st
+                k += st.kernel_ms
+                segs += st.segments
+            print(json.dumps({"ranks": G, "pipelined": pipelined, "wall_ms_per_step": round(wall, 3),
+                              "kernel_ms": round(k / args.steps, 3), "overhead_ms": round(wall - k / args.steps, 3),
+                              "mrays_s_if_all_ranks_alike": round(G * segs / args.steps / wall / 1e3, 1)}))
     scene.close()
 
 
