@@ -201,6 +201,56 @@ def main():
         cam, partition.gpu_render_rows(scene, pixels_per_pool=args.pixels_per_pool, variant=args.variant),
         partition.gpu_alloc(local_rank), rank=rank, world_size=world)
 
+    # ---- the legs beside the headline figure, before the timed steps (a GPU that has just run them flat out for
+    # seconds clocks lower): the timed kernel alone, the brute-force scan, the f64 kernel ----
+    n_spheres = len(spheres)
+    scan = {0: "grid" if n_spheres - 1 >= 40 else "hybrid", 1: "scalar", 2: "hybrid", 3: "grid"}[args.variant]
+    applies = world == 1 and full_size and args.pixels_per_pool == 0 and not args.no_refill
+    extras = {}
+    extra = world == 1 and not args.no_extra_legs and args.mode == "f32"
+    if extra:
+        # one pass of the timed kernel into fresh buffers: the image the other legs are compared with
+        c32, r32, n32 = ddev.alloc_buffers(cam, local_rank)
+        ddev.render_device(cam, scene, c32, r32, n32, pixels_per_pool=args.pixels_per_pool, variant=args.variant)   # warm-up
+        c32.zero_(); r32.zero_(); n32.zero_()
+        alone = ddev.render_device(cam, scene, c32, r32, n32, pixels_per_pool=args.pixels_per_pool, variant=args.variant)
+        extras["alone"] = {"kernel_ms": alone.kernel_ms, "resolve_ms": alone.resolve_ms,
+                           "note": "one launch of the timed kernel with nothing else on the GPU (in the timed steps a launch "
+                                   "begins while the one before it runs out, which its own duration then includes)"}
+    if extra and scan == "grid" and n_spheres <= 2048:
+        # the same frame through the scan that performs all 18 x spheres x segments flops (identical image)
+        cb, rb, nb = ddev.alloc_buffers(cam, local_rank)
+        ddev.render_device(cam, scene, cb, rb, nb, variant=d.SCAN_HYBRID)   # warm-up
+        cb.zero_(); rb.zero_(); nb.zero_()
+        bst = ddev.render_device(cam, scene, cb, rb, nb, variant=d.SCAN_HYBRID)
+        b_s = bst.kernel_ms / 1e3
+        b_ach = FLOP_PER_TEST * n_spheres * bst.segments / b_s if b_s > 0 else 0.0
+        extras["roofline_bruteforce"] = {
+            "bound": "valu", "achieved": b_ach / 1e12, "peak": PEAK_FP32_VALU / 1e12, "unit": "TFLOP/s",
+            "frac": b_ach / PEAK_FP32_VALU, "kernel": "render_f32_kernel<2> (hybrid scan: every test executed)",
+            "kernel_ms": bst.kernel_ms, "mrays_s": bst.segments / b_s / 1e6 if b_s > 0 else 0.0,
+            "work": "18 FLOP x spheres x segments of one launch, over its HIP-event duration",
+            "image_equals_default_scan": bool((cb == c32).all().item() and (rb == r32).all().item())}
+        del cb, rb, nb
+    if extra:
+        # the same frame at the reference's precision (vec3.rs:8-10): the f64 kernel (reference operation order, the
+        # frame run as a stream of samples), one launch
+        cam64 = make_cam(width=width, spp=spp, depth=depth)
+        cam64.lookfrom, cam64.focus_dist, cam64.seed, cam64.mode = cam.lookfrom, cam.focus_dist, args.seed, d.MODE_F64
+        c64, r64, n64 = ddev.alloc_buffers(cam64, local_rank)
+        st64 = ddev.render_device(cam64, scene, c64, r64, n64)
+        k64 = st64.kernel_ms / 1e3
+        cnt64, cur64, cf64 = committed_counters(args.config, "render_f64_stream_kernel") if applies else (None, False, None)
+        leg = executed_roofline(cnt64, cur64, cf64, "render_f64_stream_kernel<false>", k64, PEAK_FP64_VALU, f64=True)
+        leg.update({"dtype": "f64", "mrays_s": st64.segments / k64 / 1e6 if k64 > 0 else 0.0, "segments": int(st64.segments),
+                    "launches": 1})
+        shifts = torch.tensor([16, 8, 0], device=c64.device)
+        d8 = ((c64.view(-1, 1) >> shifts) & 255) - ((c32.view(-1, 1) >> shifts) & 255)
+        worst = d8.abs().max(dim=1).values
+        leg["f32_image_vs_this"] = {"within_1_lsb": float((worst <= 1).float().mean().item()), "max_lsb": int(worst.max().item())}
+        extras["f64_leg"] = leg
+        del c64, r64, n64, c32, r32, n32
+
     def sync():
         if world > 1:
             dist.barrier()
@@ -254,16 +304,13 @@ def main():
         total_segs, total_samples = float(segs), float(samples)
 
     if rank == 0:
-        n_spheres = len(spheres)
         k_s = my_kernel_ms / 1e3                                 # this rank's average trace-kernel duration
-        scan = {0: "grid" if n_spheres - 1 >= 40 else "hybrid", 1: "scalar", 2: "hybrid", 3: "grid"}[args.variant]
         scan_id = {"scalar": 1, "hybrid": 2, "grid": 3}[scan]
         kernel = "render_f32_kernel<%d>" % scan_id if args.mode == "f32" else (
             "render_f64_stream_kernel" if args.mode == "f64" else "render_ref_kernel<float>")
         flops_per_launch = FLOP_PER_TEST * n_spheres * (segs / max(args.steps, 1))
         ref_equiv = flops_per_launch / k_s if k_s > 0 else 0.0
         # counters apply to the configuration they were taken on: one GPU, this config at full size, default options
-        applies = world == 1 and full_size and args.pixels_per_pool == 0 and not args.no_refill
         cnt, current, cfile = committed_counters(args.config, kernel) if applies else (None, False, None)
         headline = args.config == 3
         out = {
@@ -312,45 +359,10 @@ def main():
                 "note": "18 FLOP x spheres x segments, the work of the reference's linear scan (hittable_list.rs:65-70), over "
                         "this kernel's duration.  The kernel does not execute it (the grid walk finds the same closest hit "
                         "from a few tests), so this is a speed-up figure, not a utilisation"}
-        out["roofline"]["resolve_ms"] = resolve_ms / max(args.steps, 1)
-        extra = world == 1 and not args.no_extra_legs and args.mode == "f32"
-        if extra:
-            # one pass of the timed kernel into fresh buffers: the image the other legs are compared with
-            c32, r32, n32 = ddev.alloc_buffers(cam, local_rank)
-            ddev.render_device(cam, scene, c32, r32, n32, pixels_per_pool=args.pixels_per_pool, variant=args.variant)
-        if extra and scan == "grid" and n_spheres <= 2048:
-            # the same frame through the scan that performs all 18 x spheres x segments flops (identical image)
-            cb, rb, nb = ddev.alloc_buffers(cam, local_rank)
-            ddev.render_device(cam, scene, cb, rb, nb, variant=d.SCAN_HYBRID)   # warm-up
-            cb.zero_(); rb.zero_(); nb.zero_()
-            bst = ddev.render_device(cam, scene, cb, rb, nb, variant=d.SCAN_HYBRID)
-            b_s = bst.kernel_ms / 1e3
-            b_ach = FLOP_PER_TEST * n_spheres * bst.segments / b_s if b_s > 0 else 0.0
-            out["roofline_bruteforce"] = {
-                "bound": "valu", "achieved": b_ach / 1e12, "peak": PEAK_FP32_VALU / 1e12, "unit": "TFLOP/s",
-                "frac": b_ach / PEAK_FP32_VALU, "kernel": "render_f32_kernel<2> (hybrid scan: every test executed)",
-                "kernel_ms": bst.kernel_ms, "mrays_s": bst.segments / b_s / 1e6 if b_s > 0 else 0.0,
-                "work": "18 FLOP x spheres x segments of one launch, over its HIP-event duration",
-                "image_equals_default_scan": bool((cb == c32).all().item() and (rb == r32).all().item())}
-            del cb, rb, nb
-        if extra:
-            # the same frame at the reference's precision (vec3.rs:8-10): the f64 kernel (reference operation order, the
-            # frame run as a stream of samples), one launch
-            cam64 = make_cam(width=width, spp=spp, depth=depth)
-            cam64.lookfrom, cam64.focus_dist, cam64.seed, cam64.mode = cam.lookfrom, cam.focus_dist, args.seed, d.MODE_F64
-            c64, r64, n64 = ddev.alloc_buffers(cam64, local_rank)
-            st64 = ddev.render_device(cam64, scene, c64, r64, n64)
-            k64 = st64.kernel_ms / 1e3
-            cnt64, cur64, cf64 = committed_counters(args.config, "render_f64_stream_kernel") if applies else (None, False, None)
-            leg = executed_roofline(cnt64, cur64, cf64, "render_f64_stream_kernel<false>", k64, PEAK_FP64_VALU, f64=True)
-            leg.update({"dtype": "f64", "mrays_s": st64.segments / k64 / 1e6 if k64 > 0 else 0.0, "segments": int(st64.segments),
-                        "launches": 1})
-            shifts = torch.tensor([16, 8, 0], device=c64.device)
-            d8 = ((c64.view(-1, 1) >> shifts) & 255) - ((c32.view(-1, 1) >> shifts) & 255)
-            worst = d8.abs().max(dim=1).values
-            leg["f32_image_vs_this"] = {"within_1_lsb": float((worst <= 1).float().mean().item()), "max_lsb": int(worst.max().item())}
-            out["f64_leg"] = leg
-            del c64, r64, n64, c32, r32, n32
+        if "alone" in extras:
+            out["roofline"]["kernel_ms_alone"] = extras["alone"]["kernel_ms"]
+            out["roofline"]["resolve_ms"] = extras["alone"]["resolve_ms"]
+        out.update(extras)
         if args.verify_image:
             one = partition.DistributedRenderer(
                 cam, partition.gpu_render_rows(scene, pixels_per_pool=args.pixels_per_pool, variant=args.variant),
