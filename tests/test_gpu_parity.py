@@ -1118,6 +1118,44 @@ def test_rccl_gather_on_one_gpu(dray, gpu):
         dist.destroy_process_group()
 
 
+def test_renders_enqueued_back_to_back(dray, gpu):
+    """dray_render_device_async / dray_scene_collect: twenty passes of 3 samples enqueued without a wait in between (the
+    trace kernels alternate between the scene's two trace spaces and overlap at their ends) leave the buffers that
+    one call of 60 samples leaves, bit for bit; the tickets' statistics add up to that call's; a ticket older than the
+    scene's sixteen call slots is refused; the f64 mode goes through the same entry point."""
+    spheres = dray.scene_final(1)
+    cam = dray.camera_final(width=160, spp=60, depth=50)
+    cam.mode = dray.MODE_F32
+    whole = render_gpu(dray, gpu, spheres, cam, seed=41)
+    scene = gpu.DeviceScene(spheres, 0)
+    color, raw, count = gpu.alloc_buffers(cam, 0)
+    cam.samples_per_pixel = 3
+    tickets = [gpu.render_device(cam, scene, color, raw, count, seed=41, sample_offset=3 * k, want_stats="later")
+               for k in range(20)]
+    assert [t.number for t in tickets] == list(range(1, 21))
+    late = [t.stats() for t in tickets[4:]]
+    assert (gpu.color_to_numpy(color) == whole[0]).all() and (raw.cpu().numpy() == whole[1]).all()
+    assert (count.cpu().numpy() == whole[2]).all()
+    with pytest.raises(dray.DrayError):
+        tickets[0].stats()   # twenty calls ago: its slot has served again
+    first = 0
+    for k in range(4):       # the same four passes once more into scratch buffers, for their statistics
+        c2, r2, n2 = gpu.alloc_buffers(cam, 0)
+        first += gpu.render_device(cam, scene, c2, r2, n2, seed=41, sample_offset=3 * k).segments
+    assert first + sum(st.segments for st in late) == whole[3].segments
+    assert sum(st.samples for st in late) == 16 * 3 * 160 * 90 and all(st.kernel_ms > 0 for st in late)
+    # f64: two passes enqueued back to back add up like one call
+    cam.mode, cam.samples_per_pixel = dray.MODE_F64, 6
+    whole64 = render_gpu(dray, gpu, spheres, cam, seed=41)
+    color, raw, count = gpu.alloc_buffers(cam, 0)
+    cam.samples_per_pixel = 3
+    a = gpu.render_device(cam, scene, color, raw, count, seed=41, want_stats="later")
+    b = gpu.render_device(cam, scene, color, raw, count, seed=41, sample_offset=3, want_stats="later")
+    assert a.stats().segments + b.stats().segments == whole64[3].segments
+    assert (gpu.color_to_numpy(color) == whole64[0]).all() and (raw.cpu().numpy() == whole64[1]).all()
+    scene.close()
+
+
 def test_f64_stream_kernel_shapes_of_work(dray, gpu, oracle):
     """The f64 kernel that runs the frame as a stream of samples (the default of DRAY_MODE_F64) against the
     one-thread-per-pixel kernel and the oracle, bit for bit, where its bookkeeping is under strain: one sample per
