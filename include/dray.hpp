@@ -340,6 +340,23 @@ inline void render_device(const Camera& cam, const DeviceScene& world, uint32_t*
           "render_device");
 }
 
+// The same, for renders enqueued one behind the other without a wait (the passes of a progressive render): returns the
+// call's ticket (0: nothing to render); render_collect waits for that call and returns its statistics.  A scene
+// remembers its last 16 calls.
+inline uint64_t render_device_async(const Camera& cam, const DeviceScene& world, uint32_t* d_color, double* d_raw,
+                                    int32_t* d_count, size_t buf_len, void* stream = nullptr) {
+    const dray_camera c = cam.pod();
+    uint64_t ticket = 0;
+    check(dray_render_device_async(&c, world.handle(), d_color, d_raw, d_count, buf_len, &cam.opts, stream, &ticket),
+          "render_device_async");
+    return ticket;
+}
+inline dray_stats render_collect(const DeviceScene& world, uint64_t ticket) {
+    dray_stats st{};
+    check(dray_scene_collect(world.handle(), ticket, &st), "render_collect");
+    return st;
+}
+
 using PixelIndexEntry = dray_pixel_index; // camera.rs:8-13
 using RayColorEntry = dray_path_entry;    // camera.rs:15-38 (entry and status in one record)
 
