@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Random scenes through the three sphere-scan formulations of the f32 kernel: the images, sums and segment counts of
-the grid and hybrid scans must equal the scalar scan's (exact test on every sphere) bit for bit.
+the grid and hybrid scans must equal the scalar scan's (exact test on every sphere) bit for bit.  With --mode f64:
+through the three organisations of the f64 render, likewise.
 
     python tools/fuzz_scans.py [--scenes 100] [--seed 0]
 """
@@ -63,6 +64,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--scenes", type=int, default=100)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--mode", default="f32", choices=["f32", "f64"],
+                    help="f64: the f64 render's three organisations (whole list, one thread per pixel, stream of samples), "
+                         "both product orders in turn")
     args = ap.parse_args()
     import dray_amd as d
     from dray_amd import device as ddev
@@ -70,6 +74,8 @@ def main():
     bad = 0
     for k in range(args.scenes):
         sp, cam, what = random_scene(rng, d)
+        if args.mode == "f64":
+            cam.mode, cam.flags = d.MODE_F64, (d.FLAG_ITERATIVE_PRODUCT if k % 2 else 0)
         scene = ddev.DeviceScene(sp, 0)
         res = {}
         for variant in (d.SCAN_SCALAR, d.SCAN_HYBRID, d.SCAN_GRID):
