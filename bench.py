@@ -33,7 +33,8 @@ FLOP_PER_TEST = 18.0          # reject-path flops of one ray-sphere test (sphere
 PEAK_FP32_VALU = 157.3e12     # MI355X vector FP32 peak, FLOP/s: 1024 SIMDs x 32 lanes x 2 FLOP x 2.4 GHz
 PEAK_FP64_VALU = 78.6e12      # vector FP64 peak
 FLOP_PER_ISSUE_SLOT = 128.0   # one wave64 vector instruction = 64 lanes x 2 FLOP (an FMA) at the peak above
-KERNEL_SOURCES = ("render_f32.hip", "render_ref.hip", "dray_device.h", "dray_internal.h", "dray_api.hip")
+KERNEL_SOURCES = ("render_f32.hip", "render_ref.hip", "render_f64.hip", "ref_device.h", "dray_device.h", "dray_internal.h",
+                  "dray_api.hip")
 
 # BASELINE.json's configurations that run on a GPU: scene, camera, frame
 CONFIGS = {

@@ -1,6 +1,6 @@
 // C ABI of libdray_hip.so (declared in include/dray.h): argument checking, the
 // host-side camera set-up, scene upload and launch sequencing.  Host code only;
-// the kernels live in render_ref.hip and render_f32.hip.  Build with
+// the kernels live in render_ref.hip, render_f64.hip and render_f32.hip.  Build with
 // -ffp-contract=off: the camera maths below must round like the reference's
 // plain f64 expressions (src/raytracer/camera.rs:169-206).
 #pragma clang fp contract(off)

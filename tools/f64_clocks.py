@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Where a wave of the f64 stream kernel spends its time: shader clocks per section of the main loop, summed over
 waves, from a diagnostic build with -DDRAY_F64_CLOCKS
-(tools/build_variant_lib.sh clocks render_ref "-DDRAY_F64_CLOCKS" -> tools/ab_libs/clocks.so).
+(tools/build_variant_lib.sh clocks render_f64 "-DDRAY_F64_CLOCKS" -> tools/ab_libs/clocks.so).
 
     DRAY_HIP_LIB=tools/ab_libs/clocks.so python tools/f64_clocks.py [--config 3] [--spp N]
 """
