@@ -1,26 +1,18 @@
-// The f64 render as a stream of samples, for gfx950 (the default kernel of DRAY_MODE_F64): the reference's arithmetic
-// in the reference's order (ref_device.h), organised like the f32 throughput kernel.  Build with -ffp-contract=off.
-#pragma clang fp contract(off)
-
-#include <mutex>
-
-#include "ref_device.h"
-
-namespace dray {
-namespace {
-
-// ---- the f64 render as a stream of samples -----------------------------------------------------------------
+// The f64 render as a stream of samples, for gfx950: the default kernel of DRAY_MODE_F64.  The reference's arithmetic
+// in the reference's order (ref_device.h), so that sums, colours and segment counts equal the CPU oracle's bit for
+// bit.  Build with -ffp-contract=off.
 //
-// render_ref_kernel above gives every pixel a thread that runs the pixel's loop on its own.  Its lanes wait for each
-// other wherever their trip counts differ -- the grid walk (one to dozens of cells), a cell's sphere list, the
-// rejection samplers -- and a wave lives as long as its dearest pixel takes for all of its samples, so that the
+// render_ref_kernel (render_ref.hip) gives every pixel a thread that runs the pixel's loop on its own.  Its lanes wait
+// for each other wherever their trip counts differ -- the grid walk (one to dozens of cells), a cell's sphere list,
+// the rejection samplers -- and a wave lives as long as its dearest pixel takes for all of its samples, so that the
 // machine is half empty for much of a launch.  The kernel below computes the same values and adds them in the same
 // order, organised like the f32 throughput kernel (render_f32.hip):
 //   * one persistent launch; a wave draws chunks of consecutive pixels from a global queue and hands their samples,
 //     in order, to whichever of its lanes is free: a lane carries one sample's path;
 //   * a lane's walk through the grid is kept in registers across turns of the main loop; the wave takes walk steps
-//     (one action per lane and step: leave a cell, or test one listed sphere) only while enough lanes are walking,
-//     then the lanes whose walk is over are shaded and given their next ray while the long walks go on;
+//     (a step takes a lane out of a finished cell into the next, and tests one listed sphere) only while enough
+//     lanes are walking, then the lanes whose walk is over are shaded and given their next ray while the long walks
+//     go on;
 //   * the two rejection samplers (vec3.rs:76-84, 111-118) are evaluated by the whole wave: lanes whose first attempt
 //     failed hand their stream to server lanes, which try the following blocks in parallel; the lane takes the
 //     accepted attempt with the smallest index -- the one its own loop would have stopped at;
@@ -30,9 +22,17 @@ namespace {
 // wave's stream, and the wave retires the ring in stream order: the pixel's running sum takes the colours of
 // samples 0, 1, 2, ... exactly as the per-pixel loop does.  A lane may not take a sample more than a ring's length
 // ahead of the oldest unfinished one.
-// Closest hit: as list_hit_grid (minimum over (root, list position) of sphere_root's roots over the wide, the loose
-// and the walked spheres).  A ray that is not finite, or a walk that outlasts a straight line, takes the scan of
-// the whole list, as there.
+// Closest hit: as list_hit_grid in ref_device.h (minimum over (root, list position) of sphere_root's roots over the
+// wide, the loose and the walked spheres).  A ray that is not finite, or a walk that outlasts a straight line, takes
+// the scan of the whole list, as there.
+#pragma clang fp contract(off)
+
+#include <mutex>
+
+#include "ref_device.h"
+
+namespace dray {
+namespace {
 
 // Pointer into the constant address space: a wave-uniform read through it is a scalar load.
 #define DRAY_CONSTANT __attribute__((address_space(4)))
@@ -187,7 +187,6 @@ void render_f64_stream_kernel(F64Args) {
     __shared__ uint32_t lds_fifo[4][kFifoSlots]; // first pixel of the chunks the wave has grabbed, oldest first
     __shared__ double lds_stage[4][64][3];       // the colours of the samples being retired
     const int lane = (int)(threadIdx.x & 63u), wv = (int)(threadIdx.x >> 6);
-    
     const uint32_t W = (uint32_t)ka->cam.W, spp = (uint32_t)ka->cam.spp, npix = (uint32_t)ka->part.n_rows * W;
     constexpr bool iterative = ITERATIVE; // how a sample's attenuations are multiplied (camera.rs:130 or :274)
     RingEntry* ring = ka->rings + (size_t)(blockIdx.x * 4u + (uint32_t)wv) * kF64RingEntries;
