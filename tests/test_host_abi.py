@@ -291,6 +291,10 @@ def test_entry_points_reject_bad_arguments(dray):
     assert L.dray_scene_create(sp.ctypes.data, n, -1, None) == INV
     L.dray_scene_destroy(None)   # a no-op, like free(NULL)
     assert L.dray_render_device(C.byref(cam), None, color.ctypes.data, None, None, color.size, C.byref(opts), None, None) == INV
+    ticket = C.c_uint64(7)
+    assert L.dray_render_device_async(C.byref(cam), None, color.ctypes.data, None, None, color.size, C.byref(opts), None,
+                                      C.byref(ticket)) == INV and ticket.value == 0
+    assert L.dray_scene_collect(None, 1, C.byref(_ffi.Stats())) == INV
     assert L.dray_camera_rays(None, None, 1, None, None) == INV
     assert L.dray_path_step(None, 10, None, 1, None, None) == INV
     assert L.dray_camera_rays_device(None, None, 1, None, None, None) == INV
