@@ -641,11 +641,12 @@ def test_f64_kernel_matches_oracle_on_random_scenes(dray, gpu, oracle):
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     from fuzz_scans import random_scene
-    rng = np.random.default_rng(5)
+    # (DRAY_FUZZ_SCENES / DRAY_FUZZ_SEED: longer one-off runs of the same loop)
+    rng = np.random.default_rng(int(os.environ.get("DRAY_FUZZ_SEED", "5")))
     within = total = 0
     worst = (1.0, None)
     seg32 = seg64 = 0
-    for k in range(60):
+    for k in range(int(os.environ.get("DRAY_FUZZ_SCENES", "60"))):
         sp, cam, what = random_scene(rng, dray)
         cam.mode = dray.MODE_F64
         cam.flags = dray.FLAG_ITERATIVE_PRODUCT if k % 2 else 0
