@@ -1203,6 +1203,59 @@ def test_f64_stream_kernel_shapes_of_work(dray, gpu, oracle):
     assert (count.cpu().numpy()[:H] == 9).all()
 
 
+def test_f64_organisations_agree_on_degenerate_cameras_and_scenes(dray, gpu, oracle):
+    """Inputs at the edges, through the f64 render's three organisations (stream of samples, one thread per pixel with
+    the grid, one thread per pixel over the whole list) and, where the oracle finishes in seconds, against it: a camera
+    whose position is NaN or infinite (every ray takes the whole-list scan; the sums come out NaN as in the
+    reference), a camera 1e12 units away, one inside the ground sphere, a field of view of 1e-6 and of 179.9 degrees,
+    a defocus disk wider than the scene, depth 0 and 1, spheres with NaN / zero / infinite centres or radii, a list of
+    wide spheres only, an empty list.  Equal means equal bit patterns, except that any NaN equals any NaN: the sign
+    and payload of a NaN that an operation produces are not fixed by IEEE 754 and differ between the three kernels'
+    instruction selections (and between them and the host's SSE2) though the operations are the same."""
+    def same_sums(x, y):
+        return (((x.view(np.uint64) == y.view(np.uint64)) | (np.isnan(x) & np.isnan(y)))).all()
+
+    def same(a, b):
+        return (a[0] == b[0]).all() and same_sums(a[1], b[1]) and (a[2] == b[2]).all() \
+            and a[3].segments == b[3].segments and a[3].samples == b[3].samples
+
+    final = dray.scene_final(1)
+    odd = final.copy()
+    odd["center"][5] = (np.nan, 0.0, 0.0)
+    odd["radius"][7] = np.nan
+    odd["radius"][9] = 0.0
+    odd["center"][11] = (np.inf, 0.2, 1.0)
+    odd["radius"][13] = np.inf
+    only_wide = final[:1].copy()
+    empty = final[:0].copy()
+    cases = []
+    for name, lookfrom, kw in (("nan_camera", (np.nan, 2.0, 3.0), {}), ("inf_camera", (np.inf, 2.0, 3.0), {}),
+                               ("far_camera", (1e12, 2e11, 3e11), {}), ("inside_ground", (0.0, -500.0, 0.0), {}),
+                               ("tiny_fov", (13.0, 2.0, 3.0), dict(vfov=1e-6)), ("wide_fov", (13.0, 2.0, 3.0), dict(vfov=179.9)),
+                               ("huge_defocus", (13.0, 2.0, 3.0), dict(defocus_angle=170.0)),
+                               ("depth0", (13.0, 2.0, 3.0), dict(max_depth=0)), ("depth1", (13.0, 2.0, 3.0), dict(max_depth=1))):
+        cam = dray.camera_final(width=40, spp=5, depth=12)
+        cam.lookfrom = lookfrom
+        for k, v in kw.items():
+            setattr(cam, k, v)
+        cases.append((name, final, cam))
+    for name, spheres in (("odd_spheres", odd), ("only_wide", only_wide), ("empty", empty)):
+        cases.append((name, spheres, dray.camera_final(width=40, spp=5, depth=12)))
+    for name, spheres, cam in cases:
+        cam.mode = dray.MODE_F64
+        for flags in (0, dray.FLAG_ITERATIVE_PRODUCT):
+            cam.flags = flags
+            a = render_gpu(dray, gpu, spheres, cam, seed=37)
+            b = render_gpu(dray, gpu, spheres, cam, seed=37, variant=dray.SCAN_HYBRID)
+            c = render_gpu(dray, gpu, spheres, cam, seed=37, variant=dray.SCAN_SCALAR)
+            assert same(a, b) and same(a, c), (name, flags)
+        cam.flags = 0
+        ocol, oraw, ocnt, ost = oracle.render(ocam_from(oracle, cam), spheres, seed=37, threads=8)
+        a = render_gpu(dray, gpu, spheres, cam, seed=37)
+        assert (a[0] == ocol).all() and same_sums(a[1], oraw), name
+        assert a[3].segments == ost.segments, name
+
+
 def test_headline_frame_f32_against_f64_kernel_and_oracle(dray, gpu, oracle):
     """The measured configuration at full size: final scene, 1200 x 675, 500 samples per pixel, depth 50.  The oracle
     cannot render 405 M samples in seconds, so the chain is: every 45th row of the f64 reference-order kernel's frame
