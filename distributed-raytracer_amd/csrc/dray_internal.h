@@ -166,6 +166,8 @@ struct F32Plan {
     size_t lds_bytes;         // dynamic LDS of the launch
     int32_t scan;             // the DRAY_SCAN_* formulation the launch uses (never DRAY_SCAN_AUTO)
     int32_t no_refill;        // DRAY_FLAG_NO_REFILL: idle lanes wait until their whole wave is idle
+    int32_t lds_grid;         // grid scan: the launch stages the grid's tables in LDS (workgroups of 512)
+    int32_t lds_occupancy;    // ... and so many of its workgroups fit a compute unit
 };
 F32Plan plan_render_f32(const CamDev<float>& cam, const Partition& part, int32_t pixels_per_pool, int32_t variant,
                         const SceneDev& scene, int device);

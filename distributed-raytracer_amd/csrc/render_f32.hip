@@ -44,10 +44,17 @@ constexpr int kGrabWork = 16384;               // sphere tests' worth of samples
 constexpr float kSlack = 7.62939453125e-6f;   // 2^-17, see scan_hybrid
 constexpr int kSlots = 32;                     // pixel sums a wave keeps in LDS before they go to memory
 constexpr uint32_t kNoPixel = 0xFFFFFFFFu;
+// Grid scan: lanes that must still be walking for the wave to keep stepping.  A turn of the main loop costs the same
+// whatever the number of lanes it shades, so the fewer lanes a turn leaves walking, the fewer turns a frame takes; but a
+// step costs the same whatever the number of lanes it moves.  Headline frame (ms), tables read from memory: 8 -> 26.50,
+// 12 -> 26.56, 16 -> 26.76, 24 -> 27.8 (the 10 001-sphere field at 3840x2160x64: 43.12, 42.90, 42.97); tables in LDS,
+// where a step waits less: 2 -> 26.69, 4 -> 26.00, 6 -> 25.80, 8 -> 25.77, 12 -> 25.86, 16 -> 26.06, 24 -> 27.18.
 #ifndef DRAY_WALK_QUORUM
-#define DRAY_WALK_QUORUM 16
+#define DRAY_WALK_QUORUM 12
 #endif
-constexpr int kWalkQuorum = DRAY_WALK_QUORUM;     // grid scan: lanes that must still be walking for the wave to keep stepping
+#ifndef DRAY_WALK_QUORUM_LDS
+#define DRAY_WALK_QUORUM_LDS 8
+#endif
 
 // Waves per SIMD the register allocation of the brute-force kernels aims at (8 = at most 64 VGPRs; hybrid scan,
 // 1200x675x500 frame: 7 -> 96.4 ms, 8 -> 93.8 ms) and of the grid kernel, which keeps a lane's walk alive across
@@ -292,6 +299,7 @@ __device__ __forceinline__ void scan_hybrid(const V4* lds_xy, ConstPtr<V4> filte
 }
 
 constexpr int kScanScalar = DRAY_SCAN_SCALAR, kScanHybrid = DRAY_SCAN_HYBRID, kScanGrid = DRAY_SCAN_GRID;
+constexpr int kScanGridLds = 4; // names the kernel that walks the grid from tables staged in LDS (not a caller's choice)
 
 // Grid scan: every lane walks its own ray through the uniform grid (3-D DDA) and applies the exact test to the
 // spheres listed in the cells it crosses, front to back, until the closest accepted root lies before the exit of
@@ -337,7 +345,8 @@ __device__ __forceinline__ void walk_test(Walk& w, const V4 s, int32_t pos, cons
 }
 
 // Tests the loose spheres, then places the ray in its first cell.  Returns false when there is nothing to walk.
-__device__ __forceinline__ bool walk_begin(ConstPtr<GridDev> gp, const PathRay& ray, Walk& w) {
+template <typename CellPtr>
+__device__ __forceinline__ bool walk_begin(ConstPtr<GridDev> gp, CellPtr cells, const PathRay& ray, Walk& w) {
     const DRAY_CONSTANT GridDev& g = *gp;
     w.best = kNoHit;
     ConstPtr<V4> loose_geom = as_constant((const V4*)g.loose_geom);
@@ -378,7 +387,7 @@ __device__ __forceinline__ bool walk_begin(ConstPtr<GridDev> gp, const PathRay& 
     w.e = w.e_end = 0u;
     if (walking) {
         const uint32_t ci = (uint32_t)fmaf(fmaf(w.c[2], (float)g.n[1], w.c[1]), (float)g.n[0], w.c[0]);
-        const uint2 rec = g.cells[ci];
+        const uint2 rec = cells[ci];
         w.e = rec.x;
         w.e_end = rec.x + rec.y;
     }
@@ -449,6 +458,7 @@ struct F32Args {
     int32_t pixels_per_pool;
     int32_t grab_pixels; // pixels a wave takes from the global queue per atomic (a multiple of pixels_per_pool)
     int32_t no_refill;   // idle lanes take new samples only once every lane of the wave is idle (compaction off)
+    int32_t n_cells, n_entries; // sizes of the grid's cell and entry tables (kernels that stage them in LDS)
     unsigned long long* accum;
     DeviceCounters* counters;
 };
@@ -464,8 +474,14 @@ __device__ __forceinline__ ConstPtr<T> opaque(ConstPtr<T> p) {
 // BOXES: the list holds bounding boxes (bounding_box.rs) beside its spheres.  Such a kernel carries two more values
 // per lane (the closest box of the lane's ray), so scenes without boxes -- all of the reference's render scenes --
 // run the kernels built without.
-template <int SCAN, bool BOXES>
+// LDSGRID (grid scan only): the workgroup stages the grid's cell and entry tables in LDS and its lanes walk those: a
+// walking lane's reads depend on one another (cell record, then the listed sphere), and an LDS read comes back in
+// a fraction of the time a read through the vector memory path takes.  Such a workgroup has eight waves, so that
+// three of them hold a compute unit's 24 wave slots with three copies of the tables instead of six.
+template <int SCAN, bool BOXES, bool LDSGRID>
 __device__ __forceinline__ void render_f32_body() {
+    static_assert(!LDSGRID || SCAN == kScanGrid, "only the grid scan has tables to stage");
+    constexpr int kWaves = LDSGRID ? 8 : 4; // waves of a workgroup
     // The arguments (some sixty scalar registers' worth) are read where they are used, straight from the kernel
     // argument segment, and the pointer to it is made opaque once per path segment.  Left to itself the compiler
     // loads them all above the main loop, runs out of scalar registers and spills inside the sphere scan -- where a
@@ -473,11 +489,26 @@ __device__ __forceinline__ void render_f32_body() {
     ConstPtr<F32Args> a = (ConstPtr<F32Args>)__builtin_amdgcn_kernarg_segment_ptr();
     const int lane = __lane_id();
     extern __shared__ V4 lds_xy[]; // hybrid scan: cx, cy of two consecutive narrow spheres per entry
+    // LDSGRID: the entries' geometry (16 B each), then the cell records (8 B), then the entries' list positions (4 B)
     if constexpr (SCAN == kScanHybrid) {
         const int32_t half = a->n_narrow_padded / 2;
         ConstPtr<V4> filter_xy = as_constant(a->filter_xy);
         for (int32_t k = threadIdx.x; k < half; k += blockDim.x) lds_xy[k] = filter_xy[k];
         __syncthreads(); // the only block-wide wait: every wave passes here once, before any work is drawn
+    }
+    if constexpr (LDSGRID) {
+        const int32_t n_entries = a->n_entries, n_cells = a->n_cells;
+        ConstPtr<V4> entry_geom = as_constant((const V4*)a->grid.entry_geom);
+        const uint2* cells = a->grid.cells;
+        ConstPtr<int32_t> entry_index = as_constant(a->grid.entry_index);
+        uint2* lds_cells = (uint2*)(lds_xy + n_entries);
+        int32_t* lds_index = (int32_t*)(lds_cells + n_cells);
+        for (int32_t k = threadIdx.x; k < n_entries; k += blockDim.x) {
+            lds_xy[k] = entry_geom[k];
+            lds_index[k] = entry_index[k];
+        }
+        for (int32_t k = threadIdx.x; k < n_cells; k += blockDim.x) lds_cells[k] = cells[k];
+        __syncthreads(); // as above: once, before any work is drawn
     }
 
     // A wave takes whole pixels from the global queue (a pool = all samples of `pixels_per_pool` consecutive
@@ -486,10 +517,11 @@ __device__ __forceinline__ void render_f32_body() {
     // and go to memory once, when the slot is given to a later pixel; a sample that ends after its pixel has left
     // the cache adds to memory directly.  Integer sums: the image is the same whatever the grouping.  LDS keeps
     // one wave's accesses in order, and tags and sums are only ever touched by their own wave: no barrier.
-    __shared__ unsigned long long lds_sum[4][kSlots][3]; // [wave of the block][slot][r, g, b]
-    __shared__ uint32_t lds_tag[4][kSlots];              // the slot's pixel: its Philox pixel word (j * W + i)
-    __shared__ uint4 lds_req[4][64];                     // coop_draw: streams handed to server lanes
-    static_assert(sizeof(lds_sum) + sizeof(lds_tag) + sizeof(lds_req) <= kF32StaticLds, "static LDS outgrew its budget");
+    __shared__ unsigned long long lds_sum[kWaves][kSlots][3]; // [wave of the block][slot][r, g, b]
+    __shared__ uint32_t lds_tag[kWaves][kSlots];              // the slot's pixel: its Philox pixel word (j * W + i)
+    __shared__ uint4 lds_req[kWaves][64];                     // coop_draw: streams handed to server lanes
+    static_assert(sizeof(lds_sum) + sizeof(lds_tag) + sizeof(lds_req) <= kF32StaticLds * (kWaves / 4),
+                  "static LDS outgrew its budget");
     const int wv = (int)(threadIdx.x >> 6);
     if (lane < kSlots) {
         __hip_atomic_store(&lds_tag[wv][lane], kNoPixel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -636,16 +668,24 @@ __device__ __forceinline__ void render_f32_body() {
             if constexpr (SCAN == kScanHybrid)
                 scan_hybrid(lds_xy, as_constant(a->filter_zn), as_constant(a->narrow_geom), a->n_narrow_padded, nray, sb);
             else if constexpr (SCAN == kScanGrid)
-                walking = walk_begin(&a->grid, nray, walk);
+            {
+                if constexpr (LDSGRID) walking = walk_begin(&a->grid, (const uint2*)(lds_xy + a->n_entries), nray, walk);
+                else walking = walk_begin(&a->grid, a->grid.cells, nray, walk);
+            }
             else
                 scan_scalar(as_constant(a->narrow_geom), a->n_narrow_padded, nray, sb);
             fresh = false;
         }
         if constexpr (SCAN == kScanGrid) {
             // walk until fewer than a quorum of lanes are still on their way (all of them once the queue is empty)
-            const int quorum = exhausted ? 1 : kWalkQuorum;
-            const GridRegs gr = {(float)a->grid.n[0], (float)a->grid.n[1], (float)a->grid.n[2], a->grid.cells,
-                                 (const V4*)a->grid.entry_geom, a->grid.entry_index};
+            const int quorum = exhausted ? 1 : (LDSGRID ? DRAY_WALK_QUORUM_LDS : DRAY_WALK_QUORUM);
+            GridRegs gr = {(float)a->grid.n[0], (float)a->grid.n[1], (float)a->grid.n[2], a->grid.cells,
+                           (const V4*)a->grid.entry_geom, a->grid.entry_index};
+            if constexpr (LDSGRID) {
+                gr.entry_geom = lds_xy;
+                gr.cells = (const uint2*)(lds_xy + a->n_entries);
+                gr.entry_index = (const int32_t*)(gr.cells + a->n_cells);
+            }
             PathRay nray = ray;
             nray.tmin = fmaxf(ray.tmin, 0.f); // see the origin's move above
             DRAY_CLOCK(0);
@@ -962,17 +1002,23 @@ __device__ __forceinline__ void render_f32_body() {
 template <int SCAN, bool BOXES>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DRAY_WAVES_PER_EU, DRAY_WAVES_PER_EU))) void render_f32_kernel(
     F32Args) {
-    render_f32_body<SCAN, BOXES>();
+    render_f32_body<SCAN, BOXES, false>();
 }
 template <>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DRAY_GRID_WAVES_PER_EU, DRAY_GRID_WAVES_PER_EU))) void render_f32_kernel<kScanGrid, false>(
     F32Args) {
-    render_f32_body<kScanGrid, false>();
+    render_f32_body<kScanGrid, false, false>();
 }
 template <>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DRAY_GRID_WAVES_PER_EU, DRAY_GRID_WAVES_PER_EU))) void render_f32_kernel<kScanGrid, true>(
     F32Args) {
-    render_f32_body<kScanGrid, true>();
+    render_f32_body<kScanGrid, true, false>();
+}
+// the grid scan over tables staged in LDS (scenes without boxes whose tables fit): workgroups of eight waves
+template <>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(DRAY_GRID_WAVES_PER_EU, DRAY_GRID_WAVES_PER_EU))) void render_f32_kernel<kScanGridLds, false>(
+    F32Args) {
+    render_f32_body<kScanGrid, false, true>();
 }
 
 // Adds the fixed-point sums into the caller's buffers and writes the packed colour: colors.rs:38-43.
@@ -1020,6 +1066,22 @@ F32Plan plan_render_f32(const CamDev<float>& cam, const Partition& part, int32_t
     else
         plan.scan = variant;
     plan.lds_bytes = plan.scan == DRAY_SCAN_HYBRID ? table_bytes : 0u;
+    plan.lds_grid = 0;
+    if (plan.scan == DRAY_SCAN_GRID && scene.n_boxes == 0 && scene.grid.n[0] > 0) {
+        // the staged tables: three such workgroups must fit a compute unit beside their static arrays
+        const size_t n_cells = (size_t)scene.grid.n[0] * (size_t)scene.grid.n[1] * (size_t)scene.grid.n[2];
+        const size_t bytes = scene.grid_entries * 20u + n_cells * 8u;
+        const char* env = std::getenv("DRAY_GRID_LDS"); // "0": tuning runs that want the tables read from memory
+        int occ_lds = 0;
+        if (!(env && env[0] == '0') && bytes + 2 * kF32StaticLds <= 52 * 1024 &&
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_lds, render_f32_kernel<kScanGridLds, false>, 512, bytes) == hipSuccess &&
+            occ_lds >= 3) {
+            plan.lds_grid = 1;
+            plan.block = 512;
+            plan.lds_bytes = bytes;
+            plan.lds_occupancy = occ_lds;
+        }
+    }
     // compute units of the device and resident blocks per unit of the two kernels without dynamic LDS: asked once per device
     struct DeviceFacts { int cus = 0, occ_scalar = 0, occ_grid = 0; };
     static DeviceFacts facts[64];
@@ -1032,13 +1094,14 @@ F32Plan plan_render_f32(const CamDev<float>& cam, const Partition& part, int32_t
         if (f.cus == 0) {
             int v = 0;
             f.cus = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && v > 0) ? v : 256;
-            if (occupancy_of<kScanScalar>(&v, plan.block, 0) == hipSuccess && v > 0) f.occ_scalar = v;
-            if (occupancy_of<kScanGrid>(&v, plan.block, 0) == hipSuccess && v > 0) f.occ_grid = v;
+            if (occupancy_of<kScanScalar>(&v, 256, 0) == hipSuccess && v > 0) f.occ_scalar = v;
+            if (occupancy_of<kScanGrid>(&v, 256, 0) == hipSuccess && v > 0) f.occ_grid = v;
         }
         cus = f.cus;
         occ = plan.scan == DRAY_SCAN_GRID ? f.occ_grid : plan.scan == DRAY_SCAN_SCALAR ? f.occ_scalar : 0;
     }
     if (plan.scan == DRAY_SCAN_HYBRID && occupancy_of<kScanHybrid>(&occ, plan.block, plan.lds_bytes) != hipSuccess) occ = 0;
+    if (plan.lds_grid) occ = plan.lds_occupancy;
     if (occ > 0) per_cu = occ;
     plan.grid = cus * per_cu;
     const long long npix = (long long)part.n_rows * cam.W;
@@ -1096,6 +1159,8 @@ hipError_t launch_render_f32(const CamDev<float>& cam, const SceneDev& scene, co
     args.grid = scene.grid;
     args.part = part; args.key = key; args.pixels_per_pool = plan.pixels_per_pool; args.grab_pixels = plan.grab_pixels;
     args.no_refill = plan.no_refill;
+    args.n_cells = scene.grid.n[0] * scene.grid.n[1] * scene.grid.n[2];
+    args.n_entries = (int32_t)scene.grid_entries;
     args.accum = d_accum; args.counters = d_counters;
     auto launch = [&](auto kernel) {
         hipLaunchKernelGGL(kernel, dim3(plan.grid), dim3(plan.block), plan.lds_bytes, stream, args);
@@ -1103,6 +1168,8 @@ hipError_t launch_render_f32(const CamDev<float>& cam, const SceneDev& scene, co
     const bool boxes = scene.n_boxes > 0;
     if (plan.scan == DRAY_SCAN_HYBRID)
         boxes ? launch(render_f32_kernel<kScanHybrid, true>) : launch(render_f32_kernel<kScanHybrid, false>);
+    else if (plan.scan == DRAY_SCAN_GRID && plan.lds_grid)
+        launch(render_f32_kernel<kScanGridLds, false>);
     else if (plan.scan == DRAY_SCAN_GRID)
         boxes ? launch(render_f32_kernel<kScanGrid, true>) : launch(render_f32_kernel<kScanGrid, false>);
     else

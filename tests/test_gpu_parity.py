@@ -4,6 +4,8 @@ Bars: f64 mode -- 8-bit output within 1 LSB of the oracle per channel (target 0)
 f64 running sums equal to 1e-12 relative; f32 mode -- same Philox streams, f32 arithmetic, so a stated
 share of pixels within 1 LSB plus a mean-difference bound (the tolerance is written in each test).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -47,6 +49,16 @@ def render_gpu(dray, gpu, spheres, cam, **opts):
     out = gpu.color_to_numpy(color), raw.cpu().numpy(), count.cpu().numpy(), st
     scene.close()
     return out
+
+
+def render_gpu_grid_from_memory(dray, gpu, spheres, cam, **opts):
+    """The f32 grid scan with the grid's tables read from memory even where they would fit in LDS (the kernel that
+    larger scenes and scenes with bounding boxes run); the library reads the variable at every call."""
+    os.environ["DRAY_GRID_LDS"] = "0"
+    try:
+        return render_gpu(dray, gpu, spheres, cam, variant=dray.SCAN_GRID, **opts)
+    finally:
+        del os.environ["DRAY_GRID_LDS"]
 
 
 def ocam_from(oracle, cam):
@@ -181,6 +193,8 @@ def test_f32_scan_variants_agree(dray, gpu):
         for v in (dray.SCAN_HYBRID, dray.SCAN_GRID, dray.SCAN_AUTO):
             b = render_gpu(dray, gpu, spheres, cam, seed=13, variant=v)
             assert (a[0] == b[0]).all() and (a[1] == b[1]).all() and a[3].segments == b[3].segments, v
+        b = render_gpu_grid_from_memory(dray, gpu, spheres, cam, seed=13)
+        assert (a[0] == b[0]).all() and (a[1] == b[1]).all() and a[3].segments == b[3].segments
     # a camera far from the origin: large |o| stresses the filter's slack (its error grows with |o|^2 + |c|^2)
     far = dray.camera_final(width=96, spp=12, depth=50)
     far.mode = dray.MODE_F32
@@ -233,6 +247,8 @@ def test_f32_grid_scan_equals_scalar_scan_on_random_scenes(dray, gpu):
             b = render_gpu(dray, gpu, spheres, cam, seed=19, variant=dray.SCAN_GRID)
             same = (a[0] == b[0]).all() and (a[1] == b[1]).all() and a[3].segments == b[3].segments
             assert same, (name, lookfrom, int((a[0] != b[0]).sum()), a[3].segments, b[3].segments)
+            c = render_gpu_grid_from_memory(dray, gpu, spheres, cam, seed=19)
+            assert (a[0] == c[0]).all() and (a[1] == c[1]).all() and a[3].segments == c[3].segments, (name, lookfrom)
     # degenerate inputs: zero radius, non-finite centre or radius (never hit, kept out of the grid), all spheres in
     # one spot, and an empty narrow list (only a wide sphere)
     odd = soup(rng, 120, 3.0, 0.1, 0.6)
@@ -251,6 +267,8 @@ def test_f32_grid_scan_equals_scalar_scan_on_random_scenes(dray, gpu):
         a = render_gpu(dray, gpu, spheres, cam, seed=23, variant=dray.SCAN_SCALAR)
         b = render_gpu(dray, gpu, spheres, cam, seed=23, variant=dray.SCAN_GRID)
         assert (a[0] == b[0]).all() and (a[1] == b[1]).all() and a[3].segments == b[3].segments, name
+        c = render_gpu_grid_from_memory(dray, gpu, spheres, cam, seed=23)
+        assert (a[0] == c[0]).all() and (a[1] == c[1]).all() and a[3].segments == c[3].segments, name
     # an axis-parallel bundle: zero direction components take the walk's parallel-ray branch
     cam = dray.camera_final(width=33, spp=2, depth=8)
     cam.mode = dray.MODE_F32

@@ -78,13 +78,17 @@ def main():
             cam.mode, cam.flags = d.MODE_F64, (d.FLAG_ITERATIVE_PRODUCT if k % 2 else 0)
         scene = ddev.DeviceScene(sp, 0)
         res = {}
-        for variant in (d.SCAN_SCALAR, d.SCAN_HYBRID, d.SCAN_GRID):
+        # "memory": the f32 grid scan with its tables read from memory even where they would fit in LDS
+        for variant in (d.SCAN_SCALAR, d.SCAN_HYBRID, d.SCAN_GRID) + (("memory",) if args.mode == "f32" else ()):
             color, raw, count = ddev.alloc_buffers(cam, 0)
-            st = ddev.render_device(cam, scene, color, raw, count, variant=variant)
+            if variant == "memory":
+                os.environ["DRAY_GRID_LDS"] = "0"
+            st = ddev.render_device(cam, scene, color, raw, count, variant=d.SCAN_GRID if variant == "memory" else variant)
+            os.environ.pop("DRAY_GRID_LDS", None)
             res[variant] = (ddev.color_to_numpy(color).copy(), raw.cpu().numpy().copy(), st.segments)
         scene.close()
         ok = all((res[v][0] == res[d.SCAN_SCALAR][0]).all() and (res[v][1] == res[d.SCAN_SCALAR][1]).all()
-                 and res[v][2] == res[d.SCAN_SCALAR][2] for v in (d.SCAN_HYBRID, d.SCAN_GRID))
+                 and res[v][2] == res[d.SCAN_SCALAR][2] for v in res)
         info = d.grid_inspect(sp)[0]
         if not ok:
             bad += 1

@@ -55,6 +55,10 @@ def merge(pass_dir, config, out_path):
             break
     if bench:
         timed = bench["roofline"]["kernel"].split(" ")[0]
+        # (the bench names the grid kernel from the committed counters: before the first pass over a scene whose tables
+        # are staged in LDS it says <3> where <4> ran)
+        if timed == "render_f32_kernel<3>" and timed not in kernels and "render_f32_kernel<4>" in kernels:
+            timed = "render_f32_kernel<4>"
         if timed in kernels:
             kernels[timed]["kernel_ms_under_counters"] = bench["roofline"]["kernel_ms"]
         if "roofline_bruteforce" in bench and "render_f32_kernel<2>" in kernels and timed != "render_f32_kernel<2>":
