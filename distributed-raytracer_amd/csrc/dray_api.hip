@@ -525,6 +525,7 @@ int scene_create_impl(const dray_sphere* sp, size_t n, int32_t device, dray_scen
     d.grid.entry_pos = d.grid_entry_pos;
     d.grid.loose = d.grid_loose;
     d.grid_entries = grid.entry_pos.size();
+    for (const uint2& c : grid.cells) d.grid_max_cell_entries = c.y > d.grid_max_cell_entries ? c.y : d.grid_max_cell_entries;
     { // the grid's lists once more with list positions and f64 geometry, for the f64 stream kernel
         std::vector<double> eg(4 * grid.entry_pos.size());
         std::vector<int32_t> ei(grid.entry_pos.size());

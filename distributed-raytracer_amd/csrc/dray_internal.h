@@ -101,6 +101,7 @@ struct SceneDev {
     int32_t* loose_index = nullptr;
     double* wide_geom64 = nullptr;
     size_t grid_entries = 0;
+    uint32_t grid_max_cell_entries = 0; // the longest cell list
     GridDev grid{};
     // the same lists for the f64 stream kernel, with the f64 geometry beside them so that a test costs one load:
     double* entry_geom64 = nullptr;   // per grid entry: cx, cy, cz, radius
@@ -114,6 +115,8 @@ struct SceneDev {
 // for the hybrid scan, the staged cx,cy table (8 B per sphere).  Larger tables take another scan.
 constexpr size_t kF32StaticLds = 8 * 1024;                       // budget of the static arrays (asserted in the kernel)
 constexpr size_t kHybridLdsLimit = 64 * 1024 - kF32StaticLds;    // largest table: 7 168 narrow spheres
+// The grid scan's compact copy of the grid in LDS: six workgroups are resident on a compute unit (160 KiB of LDS).
+constexpr size_t kGridLdsLimit = 160 * 1024 / 6 - kF32StaticLds - 512;
 
 struct DeviceCounters {
     unsigned long long segments;
@@ -166,8 +169,8 @@ struct F32Plan {
     size_t lds_bytes;         // dynamic LDS of the launch
     int32_t scan;             // the DRAY_SCAN_* formulation the launch uses (never DRAY_SCAN_AUTO)
     int32_t no_refill;        // DRAY_FLAG_NO_REFILL: idle lanes wait until their whole wave is idle
-    int32_t lds_grid;         // grid scan: the launch stages the grid's tables in LDS (workgroups of 512)
-    int32_t lds_occupancy;    // ... and so many of its workgroups fit a compute unit
+    int32_t lds_grid;         // grid scan: the launch's workgroups stage a compact copy of the grid in LDS
+    int32_t lds_occupancy;    // ... and so many of them fit a compute unit
 };
 F32Plan plan_render_f32(const CamDev<float>& cam, const Partition& part, int32_t pixels_per_pool, int32_t variant,
                         const SceneDev& scene, int device);

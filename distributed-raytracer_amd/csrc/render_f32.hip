@@ -47,8 +47,8 @@ constexpr uint32_t kNoPixel = 0xFFFFFFFFu;
 // Grid scan: lanes that must still be walking for the wave to keep stepping.  A turn of the main loop costs the same
 // whatever the number of lanes it shades, so the fewer lanes a turn leaves walking, the fewer turns a frame takes; but a
 // step costs the same whatever the number of lanes it moves.  Headline frame (ms), tables read from memory: 8 -> 26.50,
-// 12 -> 26.56, 16 -> 26.76, 24 -> 27.8 (the 10 001-sphere field at 3840x2160x64: 43.12, 42.90, 42.97); tables in LDS,
-// where a step waits less: 2 -> 26.69, 4 -> 26.00, 6 -> 25.80, 8 -> 25.77, 12 -> 25.86, 16 -> 26.06, 24 -> 27.18.
+// 12 -> 26.56, 16 -> 26.76, 24 -> 27.8 (the 10 001-sphere field at 3840x2160x64: 43.12, 42.90, 42.97); the grid staged
+// in LDS: 6 -> 26.46, 8 -> 26.44, 12 -> 26.41, 16 -> 26.61 on one box, 8 -> 26.27 on another.
 #ifndef DRAY_WALK_QUORUM
 #define DRAY_WALK_QUORUM 12
 #endif
@@ -345,8 +345,8 @@ __device__ __forceinline__ void walk_test(Walk& w, const V4 s, int32_t pos, cons
 }
 
 // Tests the loose spheres, then places the ray in its first cell.  Returns false when there is nothing to walk.
-template <typename CellPtr>
-__device__ __forceinline__ bool walk_begin(ConstPtr<GridDev> gp, CellPtr cells, const PathRay& ray, Walk& w) {
+template <typename Grid>
+__device__ __forceinline__ bool walk_begin(ConstPtr<GridDev> gp, const Grid& view, const PathRay& ray, Walk& w) {
     const DRAY_CONSTANT GridDev& g = *gp;
     w.best = kNoHit;
     ConstPtr<V4> loose_geom = as_constant((const V4*)g.loose_geom);
@@ -387,7 +387,7 @@ __device__ __forceinline__ bool walk_begin(ConstPtr<GridDev> gp, CellPtr cells, 
     w.e = w.e_end = 0u;
     if (walking) {
         const uint32_t ci = (uint32_t)fmaf(fmaf(w.c[2], (float)g.n[1], w.c[1]), (float)g.n[0], w.c[0]);
-        const uint2 rec = cells[ci];
+        const uint2 rec = cell_record(view, ci);
         w.e = rec.x;
         w.e_end = rec.x + rec.y;
     }
@@ -401,6 +401,26 @@ struct GridRegs {
     const V4* entry_geom;
     const int32_t* entry_index;
 };
+
+// The same for a workgroup that has staged the grid in LDS, in a compact form (so that six workgroups' copies fit a
+// compute unit): a cell record is one word -- first entry (12 bits) | entry count (4 bits) | list position of the
+// first entry's sphere (16 bits) --, an entry the 16-bit list position of its sphere, and the spheres' rows (cx, cy,
+// cz, r*r) are kept once, by list position.  A lane that enters a cell has the first sphere to test from the cell's
+// record, a lane that stays in its cell reads the entry table: either way two reads that depend on one another per
+// step, as with the tables in memory.
+struct GridLds {
+    float n0, n1, n2;
+    const uint32_t* cells;
+    const V4* geom;
+    const uint16_t* entry_index;
+};
+constexpr uint32_t kLdsBeginBits = 12u, kLdsCountBits = 4u; // entries < 2^12, entries per cell < 2^4 (checked by the plan)
+
+__device__ __forceinline__ uint2 cell_record(const GridRegs& g, uint32_t ci) { return g.cells[ci]; }
+__device__ __forceinline__ uint2 cell_record(const GridLds& g, uint32_t ci) {
+    const uint32_t rec = g.cells[ci];
+    return make_uint2(rec & ((1u << kLdsBeginBits) - 1u), (rec >> kLdsBeginBits) & ((1u << kLdsCountBits) - 1u));
+}
 
 // One step of a walking lane: leave a finished cell (or stop), then test one listed sphere.  Returns false when
 // the walk is over.  Written with selects and bitwise conditions instead of nested branches: the lanes of a wave
@@ -434,6 +454,39 @@ __device__ __forceinline__ bool walk_step(const GridRegs& g, const PathRay& ray,
     return go;
 }
 
+// The same step over the copy in LDS.
+__device__ __forceinline__ bool walk_step(const GridLds& g, const PathRay& ray, Walk& w) {
+    bool go = true;
+    uint32_t idx = 0u;
+    if (w.e == w.e_end) {
+        const float tx = fmaf(w.c[0], w.A[0], w.B[0]);
+        const float ty = fmaf(w.c[1], w.A[1], w.B[1]);
+        const float tz = fmaf(w.c[2], w.A[2], w.B[2]);
+        const float t_exit = fminf(tx, fminf(ty, tz));
+        const bool stop = __uint_as_float((uint32_t)(w.best >> 32)) < fmaf(t_exit, 1.f - 3.814697265625e-6f, -w.slack);
+        const bool sx = (tx <= ty) & (tx <= tz);
+        const bool sy = !sx & (ty <= tz);
+        w.c[0] += sx ? copysignf(1.f, w.A[0]) : 0.f;
+        w.c[1] += sy ? copysignf(1.f, w.A[1]) : 0.f;
+        w.c[2] += (sx | sy) ? 0.f : copysignf(1.f, w.A[2]);
+        const float moved = sx ? w.c[0] : (sy ? w.c[1] : w.c[2]), limit = sx ? g.n0 : (sy ? g.n1 : g.n2);
+        const bool inside = (moved >= 0.f) & (moved < limit);
+        go = inside & !stop;
+        const uint32_t ci = (uint32_t)fmaf(fmaf(w.c[2], g.n1, w.c[1]), g.n0, w.c[0]);
+        const uint32_t rec = g.cells[go ? ci : 0u];
+        w.e = rec & ((1u << kLdsBeginBits) - 1u);
+        w.e_end = go ? w.e + ((rec >> kLdsBeginBits) & ((1u << kLdsCountBits) - 1u)) : w.e;
+        idx = rec >> (kLdsBeginBits + kLdsCountBits); // the new cell's first sphere
+    } else {
+        idx = g.entry_index[w.e]; // (issued beside the other lanes' cell read: the two do not depend on one another)
+    }
+    if (w.e != w.e_end) {
+        walk_test(w, g.geom[idx], (int32_t)idx, ray);
+        ++w.e;
+    }
+    return go;
+}
+
 // Everything a launch of the trace kernel is given.
 struct F32Args {
     CamDev<float> cam;
@@ -458,7 +511,7 @@ struct F32Args {
     int32_t pixels_per_pool;
     int32_t grab_pixels; // pixels a wave takes from the global queue per atomic (a multiple of pixels_per_pool)
     int32_t no_refill;   // idle lanes take new samples only once every lane of the wave is idle (compaction off)
-    int32_t n_cells, n_entries; // sizes of the grid's cell and entry tables (kernels that stage them in LDS)
+    int32_t n_cells, n_entries, n_list; // cells and entries of the grid, length of the caller's list (the kernel that stages the grid in LDS)
     unsigned long long* accum;
     DeviceCounters* counters;
 };
@@ -474,14 +527,12 @@ __device__ __forceinline__ ConstPtr<T> opaque(ConstPtr<T> p) {
 // BOXES: the list holds bounding boxes (bounding_box.rs) beside its spheres.  Such a kernel carries two more values
 // per lane (the closest box of the lane's ray), so scenes without boxes -- all of the reference's render scenes --
 // run the kernels built without.
-// LDSGRID (grid scan only): the workgroup stages the grid's cell and entry tables in LDS and its lanes walk those: a
-// walking lane's reads depend on one another (cell record, then the listed sphere), and an LDS read comes back in
-// a fraction of the time a read through the vector memory path takes.  Such a workgroup has eight waves, so that
-// three of them hold a compute unit's 24 wave slots with three copies of the tables instead of six.
+// LDSGRID (grid scan only): the workgroup stages the grid in LDS (GridLds) and its lanes walk that copy: a walking
+// lane's reads depend on one another (cell record, entry, the sphere's row), and an LDS read comes back in a fraction
+// of the time a read through the vector memory path takes.
 template <int SCAN, bool BOXES, bool LDSGRID>
 __device__ __forceinline__ void render_f32_body() {
     static_assert(!LDSGRID || SCAN == kScanGrid, "only the grid scan has tables to stage");
-    constexpr int kWaves = LDSGRID ? 8 : 4; // waves of a workgroup
     // The arguments (some sixty scalar registers' worth) are read where they are used, straight from the kernel
     // argument segment, and the pointer to it is made opaque once per path segment.  Left to itself the compiler
     // loads them all above the main loop, runs out of scalar registers and spills inside the sphere scan -- where a
@@ -489,7 +540,7 @@ __device__ __forceinline__ void render_f32_body() {
     ConstPtr<F32Args> a = (ConstPtr<F32Args>)__builtin_amdgcn_kernarg_segment_ptr();
     const int lane = __lane_id();
     extern __shared__ V4 lds_xy[]; // hybrid scan: cx, cy of two consecutive narrow spheres per entry
-    // LDSGRID: the entries' geometry (16 B each), then the cell records (8 B), then the entries' list positions (4 B)
+    // LDSGRID: the spheres' rows by list position (16 B each), then the cell records (4 B), then the entries (2 B)
     if constexpr (SCAN == kScanHybrid) {
         const int32_t half = a->n_narrow_padded / 2;
         ConstPtr<V4> filter_xy = as_constant(a->filter_xy);
@@ -497,17 +548,24 @@ __device__ __forceinline__ void render_f32_body() {
         __syncthreads(); // the only block-wide wait: every wave passes here once, before any work is drawn
     }
     if constexpr (LDSGRID) {
-        const int32_t n_entries = a->n_entries, n_cells = a->n_cells;
-        ConstPtr<V4> entry_geom = as_constant((const V4*)a->grid.entry_geom);
+        const int32_t n_entries = a->n_entries, n_cells = a->n_cells, n_list = a->n_list;
+        ConstPtr<V4> narrow_geom = as_constant(a->narrow_geom);
+        ConstPtr<int32_t> narrow_index = as_constant(a->narrow_index);
         const uint2* cells = a->grid.cells;
         ConstPtr<int32_t> entry_index = as_constant(a->grid.entry_index);
-        uint2* lds_cells = (uint2*)(lds_xy + n_entries);
-        int32_t* lds_index = (int32_t*)(lds_cells + n_cells);
-        for (int32_t k = threadIdx.x; k < n_entries; k += blockDim.x) {
-            lds_xy[k] = entry_geom[k];
-            lds_index[k] = entry_index[k];
+        uint32_t* lds_cells = (uint32_t*)(lds_xy + n_list);
+        uint16_t* lds_entries = (uint16_t*)(lds_cells + n_cells);
+        // (rows of list positions that hold no narrow sphere -- wide spheres, boxes -- are never read: no entry names them)
+        for (int32_t k = threadIdx.x; k < a->n_narrow_padded; k += blockDim.x) {
+            const int32_t at = narrow_index[k];
+            if (at >= 0 && at < n_list) lds_xy[at] = narrow_geom[k];
         }
-        for (int32_t k = threadIdx.x; k < n_cells; k += blockDim.x) lds_cells[k] = cells[k];
+        for (int32_t k = threadIdx.x; k < n_cells; k += blockDim.x) {
+            const uint2 rec = cells[k];
+            const uint32_t first = rec.y != 0u ? (uint32_t)entry_index[rec.x] : 0u;
+            lds_cells[k] = rec.x | (rec.y << kLdsBeginBits) | (first << (kLdsBeginBits + kLdsCountBits));
+        }
+        for (int32_t k = threadIdx.x; k < n_entries; k += blockDim.x) lds_entries[k] = (uint16_t)entry_index[k];
         __syncthreads(); // as above: once, before any work is drawn
     }
 
@@ -517,11 +575,10 @@ __device__ __forceinline__ void render_f32_body() {
     // and go to memory once, when the slot is given to a later pixel; a sample that ends after its pixel has left
     // the cache adds to memory directly.  Integer sums: the image is the same whatever the grouping.  LDS keeps
     // one wave's accesses in order, and tags and sums are only ever touched by their own wave: no barrier.
-    __shared__ unsigned long long lds_sum[kWaves][kSlots][3]; // [wave of the block][slot][r, g, b]
-    __shared__ uint32_t lds_tag[kWaves][kSlots];              // the slot's pixel: its Philox pixel word (j * W + i)
-    __shared__ uint4 lds_req[kWaves][64];                     // coop_draw: streams handed to server lanes
-    static_assert(sizeof(lds_sum) + sizeof(lds_tag) + sizeof(lds_req) <= kF32StaticLds * (kWaves / 4),
-                  "static LDS outgrew its budget");
+    __shared__ unsigned long long lds_sum[4][kSlots][3]; // [wave of the block][slot][r, g, b]
+    __shared__ uint32_t lds_tag[4][kSlots];              // the slot's pixel: its Philox pixel word (j * W + i)
+    __shared__ uint4 lds_req[4][64];                     // coop_draw: streams handed to server lanes
+    static_assert(sizeof(lds_sum) + sizeof(lds_tag) + sizeof(lds_req) <= kF32StaticLds, "static LDS outgrew its budget");
     const int wv = (int)(threadIdx.x >> 6);
     if (lane < kSlots) {
         __hip_atomic_store(&lds_tag[wv][lane], kNoPixel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -669,8 +726,13 @@ __device__ __forceinline__ void render_f32_body() {
                 scan_hybrid(lds_xy, as_constant(a->filter_zn), as_constant(a->narrow_geom), a->n_narrow_padded, nray, sb);
             else if constexpr (SCAN == kScanGrid)
             {
-                if constexpr (LDSGRID) walking = walk_begin(&a->grid, (const uint2*)(lds_xy + a->n_entries), nray, walk);
-                else walking = walk_begin(&a->grid, a->grid.cells, nray, walk);
+                if constexpr (LDSGRID) {
+                    const GridLds view = {0.f, 0.f, 0.f, (const uint32_t*)(lds_xy + a->n_list), lds_xy, nullptr};
+                    walking = walk_begin(&a->grid, view, nray, walk);
+                } else {
+                    const GridRegs view = {0.f, 0.f, 0.f, a->grid.cells, nullptr, nullptr};
+                    walking = walk_begin(&a->grid, view, nray, walk);
+                }
             }
             else
                 scan_scalar(as_constant(a->narrow_geom), a->n_narrow_padded, nray, sb);
@@ -679,13 +741,17 @@ __device__ __forceinline__ void render_f32_body() {
         if constexpr (SCAN == kScanGrid) {
             // walk until fewer than a quorum of lanes are still on their way (all of them once the queue is empty)
             const int quorum = exhausted ? 1 : (LDSGRID ? DRAY_WALK_QUORUM_LDS : DRAY_WALK_QUORUM);
-            GridRegs gr = {(float)a->grid.n[0], (float)a->grid.n[1], (float)a->grid.n[2], a->grid.cells,
-                           (const V4*)a->grid.entry_geom, a->grid.entry_index};
-            if constexpr (LDSGRID) {
-                gr.entry_geom = lds_xy;
-                gr.cells = (const uint2*)(lds_xy + a->n_entries);
-                gr.entry_index = (const int32_t*)(gr.cells + a->n_cells);
-            }
+            auto grid_view = [&]() {
+                if constexpr (LDSGRID) {
+                    const uint32_t* cells = (const uint32_t*)(lds_xy + a->n_list);
+                    return GridLds{(float)a->grid.n[0], (float)a->grid.n[1], (float)a->grid.n[2], cells, lds_xy,
+                                   (const uint16_t*)(cells + a->n_cells)};
+                } else {
+                    return GridRegs{(float)a->grid.n[0], (float)a->grid.n[1], (float)a->grid.n[2], a->grid.cells,
+                                    (const V4*)a->grid.entry_geom, a->grid.entry_index};
+                }
+            };
+            const auto gr = grid_view();
             PathRay nray = ray;
             nray.tmin = fmaxf(ray.tmin, 0.f); // see the origin's move above
             DRAY_CLOCK(0);
@@ -1014,9 +1080,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DRAY_GRID_W
     F32Args) {
     render_f32_body<kScanGrid, true, false>();
 }
-// the grid scan over tables staged in LDS (scenes without boxes whose tables fit): workgroups of eight waves
+// the grid scan over a copy of the grid staged in LDS (scenes without boxes whose compact tables fit)
 template <>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(DRAY_GRID_WAVES_PER_EU, DRAY_GRID_WAVES_PER_EU))) void render_f32_kernel<kScanGridLds, false>(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DRAY_GRID_WAVES_PER_EU, DRAY_GRID_WAVES_PER_EU))) void render_f32_kernel<kScanGridLds, false>(
     F32Args) {
     render_f32_body<kScanGrid, false, true>();
 }
@@ -1068,16 +1134,17 @@ F32Plan plan_render_f32(const CamDev<float>& cam, const Partition& part, int32_t
     plan.lds_bytes = plan.scan == DRAY_SCAN_HYBRID ? table_bytes : 0u;
     plan.lds_grid = 0;
     if (plan.scan == DRAY_SCAN_GRID && scene.n_boxes == 0 && scene.grid.n[0] > 0) {
-        // the staged tables: three such workgroups must fit a compute unit beside their static arrays
+        // the compact copy of the grid (GridLds): staged when six such workgroups -- the kernel's residency -- fit a
+        // compute unit's LDS beside their static arrays, and the packed fields hold the grid's numbers
         const size_t n_cells = (size_t)scene.grid.n[0] * (size_t)scene.grid.n[1] * (size_t)scene.grid.n[2];
-        const size_t bytes = scene.grid_entries * 20u + n_cells * 8u;
-        const char* env = std::getenv("DRAY_GRID_LDS"); // "0": tuning runs that want the tables read from memory
+        const size_t bytes = (size_t)scene.n * 16u + n_cells * 4u + ((scene.grid_entries * 2u + 15u) & ~(size_t)15u);
+        const char* env = std::getenv("DRAY_GRID_LDS"); // "0": the tables are read from memory (tests, tuning runs)
         int occ_lds = 0;
-        if (!(env && env[0] == '0') && bytes + 2 * kF32StaticLds <= 52 * 1024 &&
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_lds, render_f32_kernel<kScanGridLds, false>, 512, bytes) == hipSuccess &&
-            occ_lds >= 3) {
+        if (!(env && env[0] == '0') && scene.n <= 65535 && scene.grid_entries < (1u << kLdsBeginBits) &&
+            scene.grid_max_cell_entries < (1u << kLdsCountBits) && bytes <= kGridLdsLimit &&
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_lds, render_f32_kernel<kScanGridLds, false>, 256, bytes) == hipSuccess &&
+            occ_lds >= DRAY_GRID_WAVES_PER_EU) {
             plan.lds_grid = 1;
-            plan.block = 512;
             plan.lds_bytes = bytes;
             plan.lds_occupancy = occ_lds;
         }
@@ -1161,6 +1228,7 @@ hipError_t launch_render_f32(const CamDev<float>& cam, const SceneDev& scene, co
     args.no_refill = plan.no_refill;
     args.n_cells = scene.grid.n[0] * scene.grid.n[1] * scene.grid.n[2];
     args.n_entries = (int32_t)scene.grid_entries;
+    args.n_list = scene.n;
     args.accum = d_accum; args.counters = d_counters;
     auto launch = [&](auto kernel) {
         hipLaunchKernelGGL(kernel, dim3(plan.grid), dim3(plan.block), plan.lds_bytes, stream, args);
