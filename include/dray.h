@@ -137,7 +137,8 @@ enum {
     DRAY_SCAN_HYBRID = 2, /* expanded-form filter (geometry from LDS + scalar loads) in front of the exact test;
                              DRAY_ERR_UNSUPPORTED when the sphere table does not fit in LDS (> 7168 spheres) */
     DRAY_SCAN_GRID = 3    /* every lane walks its ray through a uniform grid over the spheres and applies the exact
-                             test to the spheres of the cells it crosses */
+                             test to the spheres of the cells it crosses (from a copy of the grid in LDS when six
+                             workgroups' copies fit a compute unit, from memory otherwise: the library decides) */
 };
 
 typedef struct dray_opts {
