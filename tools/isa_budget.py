@@ -62,7 +62,7 @@ def main():
                         "-save-temps", "-c", src, "-o", os.path.join(tmp, "o.o")], cwd=tmp, check=True,
                        stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         asm = open(os.path.join(tmp, "render_f32-hip-amdgcn-amd-amdhsa-gfx950.s")).read().splitlines()
-    name = "render_f32_kernelILi%dELb0E" % args.scan   # <scan, no bounding boxes>
+    name = "render_f32_kernelILi%dELb0E" % args.scan   # <scan, no bounding boxes>; 4 = the grid scan over its copy in LDS   # <scan, no bounding boxes>
     start = next(i for i, l in enumerate(asm) if l.startswith("_Z") and name in l.split(":")[0] and ":" in l)
     section, order, table = "0_entry", ["0_entry"], {}
     meta = {}
