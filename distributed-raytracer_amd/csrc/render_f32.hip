@@ -1173,7 +1173,22 @@ F32Plan plan_render_f32(const CamDev<float>& cam, const Partition& part, int32_t
     plan.grid = cus * per_cu;
     const long long npix = (long long)part.n_rows * cam.W;
     const int32_t spp = cam.spp > 0 ? cam.spp : 1;
-    int32_t ppp = pixels_per_pool > 0 ? pixels_per_pool : (kPoolSamples + spp - 1) / spp; // >= kPoolSamples samples ...
+    // the first round of grabs may take a sixteenth of the launch at most (see below)
+    const long long sixteenth = (long long)(part.n_rows > 0 ? part.n_rows : 0) * cam.W * spp /
+                                (16LL * plan.grid * (plan.block / 64));
+    int32_t ppp = (kPoolSamples + spp - 1) / spp; // >= kPoolSamples samples ...
+    if (plan.scan == DRAY_SCAN_GRID) {
+        // With the grid scan, whose samples are cheap, a pool of some 500 to 1 000 samples is the better unit: a pool is
+        // what a wave asks the queue for at least, and it waits for the answer.  1200x675 frame, ms at 1 / 2 / 4 / 8 pixels
+        // per pool: 500 spp 26.37 / 25.96 / 26.26 / -, 250 spp 13.53 / 13.39 / 13.26 / -, 100 spp 5.83 / 5.74 / 5.72 /
+        // 5.76, 50 spp (2 / 4 / 8 / 12 / 16 pixels) 3.22 / 3.23 / 3.14 / 3.16 / 3.37.  A small launch keeps small pools.
+        int32_t want = (512 + spp - 1) / spp;
+        if (want > 12) want = 12;
+        const int32_t fits = (int32_t)(sixteenth / spp < 12 ? sixteenth / spp : 12);
+        if (want > fits) want = fits;
+        if (want > ppp) ppp = want;
+    }
+    if (pixels_per_pool > 0) ppp = pixels_per_pool;
     if (ppp > kSlots / 2) ppp = kSlots / 2; // ... while the previous pool's pixels stay cached
     plan.pixels_per_pool = ppp;
     // Cheap samples drain the queue fast and need big grabs to stay under the counter's atomic rate; dear ones
@@ -1189,8 +1204,6 @@ F32Plan plan_render_f32(const CamDev<float>& cam, const Partition& part, int32_t
     // (at least 256: a 66-sphere scene at 100 spp took 10.3 ms with the hybrid scan at one pixel per grab, bound by
     // the counter, and 6.2 ms at two)
     grab_samples = grab_samples < 256 ? 256 : (grab_samples > 1024 ? 1024 : grab_samples);
-    const long long sixteenth = (long long)(part.n_rows > 0 ? part.n_rows : 0) * cam.W * (cam.spp > 0 ? cam.spp : 1) /
-                             (16LL * plan.grid * (plan.block / 64));
     // ... but not below 256 samples: at the grid scan's 15 G samples/s, 128-sample grabs ask the counter for more
     // than the 80 M returning atomics per second it serves (1200x675x10 spp: 1.81 ms at 70 samples per grab, 1.15 ms at 210)
     const int32_t least = grab_samples < 256 ? grab_samples : 256;
