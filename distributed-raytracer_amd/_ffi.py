@@ -130,13 +130,15 @@ class GridInfo(C.Structure):
                 ("max_cell_entries", C.c_uint32), ("_pad", C.c_uint32)]
 
 
+PRESENT_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int32, C.c_int32)   # dray_present_fn: user, pass, samples done
+
 EXPORTS = (
     "dray_version", "dray_strerror", "dray_device_count", "dray_opts_default", "dray_camera_default",
     "dray_camera_initialize", "dray_render", "dray_render_multi", "dray_scene_create", "dray_scene_destroy", "dray_render_device",
     "dray_scene_final", "dray_scene_recipe", "dray_scene_three_spheres", "dray_write_ppm", "dray_camera_rays",
     "dray_path_step", "dray_camera_rays_device", "dray_path_step_device", "dray_grid_inspect",
     "dray_render_device_noalloc", "dray_render_device_async", "dray_scene_collect", "dray_release_cache", "dray_context_create", "dray_context_destroy",
-    "dray_context_set_scene", "dray_context_render", "dray_context_pin", "dray_context_unpin", "dray_context_host_alloc",
+    "dray_context_set_scene", "dray_context_render", "dray_context_render_progressive", "dray_context_pin", "dray_context_unpin", "dray_context_host_alloc",
 )
 
 _lib = None
@@ -197,6 +199,8 @@ def lib():
     L.dray_context_set_scene.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     L.dray_context_render.argtypes = [C.c_void_p, P(CameraPOD), C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, P(Opts),
                                       C.c_uint32, P(Stats)]
+    L.dray_context_render_progressive.argtypes = [C.c_void_p, P(CameraPOD), C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                                  P(Opts), C.c_int32, PRESENT_FN, C.c_void_p, P(Stats)]
     L.dray_context_pin.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     L.dray_context_host_alloc.argtypes = [C.c_void_p, C.c_size_t, P(C.c_void_p)]
     L.dray_context_unpin.restype = None

@@ -981,12 +981,15 @@ int resolve_device(const dray_opts& opts, int* device) {
 // ---------------------------------------------------------------------------------------------------------------
 // A render context: everything the one-call route (host buffers in, host buffers out) would otherwise set up and tear
 // down per call, kept between calls -- per share of the frame a scene (sphere tables, grid, workspace) on its device,
-// the device-side colour / sum / count slabs, two streams and a pinned staging block.  Share k of G renders scanlines
+// the device-side colour / sum / count slabs, a stream and a pinned staging block.  Share k of G renders scanlines
 // k, k + G, ... (whole scene replicated), as dray_render_multi describes.
 struct CtxShare {
     int32_t device = 0;
     dray_scene* scene = nullptr;
-    hipStream_t compute = nullptr, copy = nullptr;
+    // One stream of its own: a GPU serves four hardware queues per process here, and with a second one in the context
+    // the scene's two trace streams came to share a queue, so that a pass could not begin while the one before it ran
+    // out (the headline frame in ten passes: 32.9 against 29.5 ms).  The sums go up on the scene's idle trace stream.
+    hipStream_t compute = nullptr;
     hipEvent_t uploaded = nullptr;
     uint32_t* d_color = nullptr;
     double* d_raw = nullptr;
@@ -997,6 +1000,22 @@ struct CtxShare {
     RenderJob job;
     dray_stats stats{};
     bool active = false;
+    // a progressive render keeps three passes under way, each on a colour route of its own: route 0 is the slab and
+    // the pinned block above, routes 1 and 2 have theirs here
+    uint32_t* d_color_more[2] = {nullptr, nullptr};
+    size_t cap_more[2] = {0, 0};
+    char* stage_more[2] = {nullptr, nullptr};
+    size_t stage_more_bytes[2] = {0, 0};
+    hipEvent_t pass_done[3] = {nullptr, nullptr, nullptr}; // the pass's results have left the device
+};
+constexpr int kCtxRoutes = 3;
+
+// One pass of a context's render between its two halves: enqueued, not yet handed to the caller.
+struct CtxPass {
+    std::vector<uint64_t> ticket; // per share: the scene's call (0: the share has no rows)
+    int buf = 0;                   // which colour route it uses
+    size_t W = 0, H = 0;
+    bool staged_color = false, staged_raw = false, staged_count = false; // rows wait in pinned blocks for the scatter
 };
 
 struct dray_context {
@@ -1019,12 +1038,15 @@ void context_free(dray_context* c) {
     for (CtxShare& sh : c->shares) {
         DeviceGuard g(sh.device);
         if (sh.compute) (void)hipStreamSynchronize(sh.compute);
-        if (sh.copy) (void)hipStreamSynchronize(sh.copy);
         (void)hipFree(sh.d_color); (void)hipFree(sh.d_raw); (void)hipFree(sh.d_count);
         if (sh.stage) (void)hipHostFree(sh.stage);
+        for (auto& d : sh.d_color_more) (void)hipFree(d);
+        for (auto& h : sh.stage_more)
+            if (h) (void)hipHostFree(h);
+        for (auto& e : sh.pass_done)
+            if (e) (void)hipEventDestroy(e);
         if (sh.uploaded) (void)hipEventDestroy(sh.uploaded);
         if (sh.compute) (void)hipStreamDestroy(sh.compute);
-        if (sh.copy) (void)hipStreamDestroy(sh.copy);
         scene_free(sh.scene);
     }
     for (auto& pin : c->pins) {
@@ -1058,7 +1080,8 @@ int context_create_impl(const int32_t* devices, int32_t n_devices, dray_context*
         DeviceGuard g(d);
         hipError_t e = g.err;
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&sh.compute, hipStreamNonBlocking);
-        if (e == hipSuccess) e = hipStreamCreateWithFlags(&sh.copy, hipStreamNonBlocking);
+        for (auto& ev : sh.pass_done)
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&sh.uploaded, hipEventDisableTiming);
         if (e != hipSuccess) {
             const int rc = hip_fail(e, "context streams");
@@ -1136,10 +1159,31 @@ int context_pin_locked(dray_context* c, void* host, size_t bytes) {
     return DRAY_OK;
 }
 
-// The whole frame into host buffers: see dray_context_render in dray.h.
-int context_render_locked(dray_context* c, const dray_camera* cam, uint32_t* color, double* raw, int32_t* count,
-                          size_t buf_len, const dray_opts* opts_in, uint32_t sync, dray_stats* stats) {
-    const auto t_begin = std::chrono::steady_clock::now();
+// image row k + r G of the caller's buffer <-> slab row r of share k; `elem` bytes per pixel
+size_t share_rows(size_t H, int32_t k, int32_t G) { return (size_t)k < H ? (H - (size_t)k + (size_t)G - 1) / (size_t)G : 0; }
+void scatter_rows(void* host, const char* stage, size_t elem, size_t W, size_t H, int32_t k, int32_t G) {
+    char* h = (char*)host + (size_t)k * W * elem;
+    const size_t row = W * elem, host_pitch = (size_t)G * row, n_rows = share_rows(H, k, G);
+    for (size_t r = 0; r < n_rows; ++r) std::memcpy(h + r * host_pitch, stage + r * row, row);
+}
+
+#define CTX_TRY(expr)                                      \
+    do {                                                   \
+        hipError_t e__ = (expr);                           \
+        if (e__ != hipSuccess) return hip_fail(e__, #expr); \
+    } while (0)
+
+// First half of a context's render: everything is enqueued -- trace kernels, the sums' way up, the kernels that read
+// them, the results' way down -- and `pass` says what is under way.  `buf` picks the colour route (1, 2: a slab and
+// a pinned block of their own, for a pass enqueued while earlier ones have not been handed out; their colours are
+// always staged).  `own_sums`: 0 none; a pass of several whose caller gave no raw / count keeps those sums in the context's
+// slabs all the same, so that the picture is the picture of all passes so far -- 1: zeroed for the first pass, 2: carried on.
+// Nothing here waits for the device.
+int context_enqueue_locked(dray_context* c, const dray_camera* cam, uint32_t* color, double* raw, int32_t* count,
+                           size_t buf_len, const dray_opts* opts_in, uint32_t sync, int buf, bool stage_color, int own_sums,
+                           CtxPass* pass) {
+    pass->ticket.assign(c->shares.size(), 0);
+    pass->buf = buf;
     if (!camera_ok(cam) || !color) return DRAY_ERR_INVALID_ARG;
     if (!c->have_scene) {
         snprintf(g_detail, sizeof g_detail, "the context has no scene: call dray_context_set_scene first");
@@ -1155,15 +1199,12 @@ int context_render_locked(dray_context* c, const dray_camera* cam, uint32_t* col
     int rc = dray_camera_initialize(cam, &dv);
     if (rc) return rc;
     const size_t W = (size_t)cam->image_width, H = (size_t)dv.image_height;
+    pass->W = W;
+    pass->H = H;
     if (buf_len < W * H) return DRAY_ERR_BUFFER_TOO_SMALL;
     const bool exact_product = opts.mode != DRAY_MODE_F32 && !(opts.flags & DRAY_FLAG_ITERATIVE_PRODUCT);
     if (exact_product && cam->max_depth > kExactMaxDepth) return DRAY_ERR_UNSUPPORTED;
     const int32_t G = (int32_t)c->shares.size();
-    if (stats) {
-        std::memset(stats, 0, sizeof *stats);
-        stats->image_height = (int32_t)H;
-        stats->n_spheres = (int32_t)c->spheres.size();
-    }
     if (cam->samples_per_pixel <= 0) return DRAY_OK; // camera.rs:217: no samples, no writes
     const bool upload = (sync & DRAY_SYNC_UPLOAD_SUMS) != 0, download = (sync & DRAY_SYNC_DOWNLOAD_SUMS) != 0;
     if (!upload && (raw || count)) {
@@ -1175,9 +1216,12 @@ int context_render_locked(dray_context* c, const dray_camera* cam, uint32_t* col
     }
     c->res_W = c->res_H = 0; // until this call has gone through
 
-    const bool direct_color = G > 0 && pinned(c, color, W * H * sizeof(uint32_t));
+    const bool direct_color = !stage_color && G > 0 && pinned(c, color, W * H * sizeof(uint32_t));
     const bool direct_raw = raw && pinned(c, raw, W * H * 3 * sizeof(double));
     const bool direct_count = count && pinned(c, count, W * H * sizeof(int32_t));
+    pass->staged_color = !direct_color;
+    pass->staged_raw = download && raw && !direct_raw;
+    pass->staged_count = download && count && !direct_count;
 
     struct Fail { // on any failure: let go of the scenes, drain what was enqueued
         dray_context* c;
@@ -1188,24 +1232,18 @@ int context_render_locked(dray_context* c, const dray_camera* cam, uint32_t* col
                 if (!sh.active) continue;
                 sh.job.abandon();
                 DeviceGuard g(sh.device);
-                (void)hipStreamSynchronize(sh.copy);
                 (void)hipStreamSynchronize(sh.compute);
                 sh.active = false;
             }
         }
     } guard{c};
-#define CTX_TRY(expr)                                      \
-    do {                                                   \
-        hipError_t e__ = (expr);                           \
-        if (e__ != hipSuccess) return hip_fail(e__, #expr); \
-    } while (0)
 
     // ---- set-up per share: slabs and staging large enough, the job checked ----------------------------------
     for (int32_t k = 0; k < G; ++k) {
         CtxShare& sh = c->shares[(size_t)k];
         sh.active = false;
         std::memset(&sh.stats, 0, sizeof sh.stats);
-        const size_t n_rows = (size_t)k < H ? (H - (size_t)k + (size_t)G - 1) / (size_t)G : 0;
+        const size_t n_rows = share_rows(H, k, G);
         if (n_rows == 0) continue;
         const size_t slab = n_rows * W;
         DeviceGuard g(sh.device);
@@ -1227,6 +1265,23 @@ int context_render_locked(dray_context* c, const dray_camera* cam, uint32_t* col
             CTX_TRY(hipHostMalloc((void**)&sh.stage, stage_need, hipHostMallocDefault));
             sh.stage_bytes = stage_need;
         }
+        if (buf > 0) { // a colour route of its own
+            const int r = buf - 1;
+            if (slab > sh.cap_more[r]) {
+                CTX_TRY(hipStreamSynchronize(sh.compute));
+                (void)hipFree(sh.d_color_more[r]);
+                sh.d_color_more[r] = nullptr; sh.cap_more[r] = 0;
+                CTX_TRY(hipMalloc((void**)&sh.d_color_more[r], slab * sizeof(uint32_t)));
+                sh.cap_more[r] = slab;
+            }
+            if (slab * sizeof(uint32_t) > sh.stage_more_bytes[r]) {
+                CTX_TRY(hipStreamSynchronize(sh.compute));
+                if (sh.stage_more[r]) (void)hipHostFree(sh.stage_more[r]);
+                sh.stage_more[r] = nullptr; sh.stage_more_bytes[r] = 0;
+                CTX_TRY(hipHostMalloc((void**)&sh.stage_more[r], slab * sizeof(uint32_t), hipHostMallocDefault));
+                sh.stage_more_bytes[r] = slab * sizeof(uint32_t);
+            }
+        }
         dray_opts o = opts;
         o.device = sh.device;
         o.row_begin = k;
@@ -1240,10 +1295,9 @@ int context_render_locked(dray_context* c, const dray_camera* cam, uint32_t* col
     for (CtxShare& sh : c->shares)
         if (sh.active && (rc = sh.job.begin())) return rc;
 
-    // image row k + r G of the caller's buffer <-> slab row r; `elem` bytes per pixel
     auto rows = [&](CtxShare& sh, int32_t k, void* dev, void* host, size_t elem, bool to_device, bool direct, char* stage,
                     hipStream_t stream) -> hipError_t {
-        const size_t n_rows = (H - (size_t)k + (size_t)G - 1) / (size_t)G;
+        const size_t n_rows = share_rows(H, k, G);
         char* h = (char*)host + (size_t)k * W * elem;
         const size_t row = W * elem, host_pitch = (size_t)G * row;
         const hipMemcpyKind kind = to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost;
@@ -1256,7 +1310,7 @@ int context_render_locked(dray_context* c, const dray_camera* cam, uint32_t* col
             for (size_t r = 0; r < n_rows; ++r) std::memcpy(stage + r * row, h + r * host_pitch, row);
             return hipMemcpyAsync(dev, stage, n_rows * row, kind, stream);
         }
-        return hipMemcpyAsync(stage, dev, n_rows * row, kind, stream); // scattered to the rows after the stream is done
+        return hipMemcpyAsync(stage, dev, n_rows * row, kind, stream); // scattered to the rows once the pass is done
     };
     // ---- the sums the render adds to go up while the trace kernels run; then the kernels that need them ---------
     for (int32_t k = 0; k < G; ++k) {
@@ -1266,47 +1320,137 @@ int context_render_locked(dray_context* c, const dray_camera* cam, uint32_t* col
         const size_t slab = (size_t)sh.job.part.n_rows * W;
         char* st_raw = sh.stage ? sh.stage + slab * sizeof(uint32_t) : nullptr;
         char* st_count = sh.stage ? st_raw + slab * 3 * sizeof(double) : nullptr;
+        uint32_t* d_color = buf > 0 ? sh.d_color_more[buf - 1] : sh.d_color;
+        char* st_color = buf > 0 ? sh.stage_more[buf - 1] : sh.stage;
+        // The way up: on the stream of the scene's other trace space, which has nothing to do until the next call's
+        // trace kernel (a copy enqueued behind this call's own kernels would be made by a kernel too, and wait with
+        // them for the compute units the trace kernel holds).
+        hipStream_t up = sh.scene->space[sh.scene->next_space].side;
         bool sent = false;
-        if (upload && raw) { CTX_TRY(rows(sh, k, sh.d_raw, raw, 3 * sizeof(double), true, direct_raw, st_raw, sh.copy)); sent = true; }
-        if (upload && count) { CTX_TRY(rows(sh, k, sh.d_count, count, sizeof(int32_t), true, direct_count, st_count, sh.copy)); sent = true; }
-        if (sent) CTX_TRY(hipEventRecord(sh.uploaded, sh.copy));
-        if ((rc = sh.job.finish(sh.d_color, raw ? sh.d_raw : nullptr, count ? sh.d_count : nullptr, sent ? sh.uploaded : nullptr)))
+        if (upload && raw) { CTX_TRY(rows(sh, k, sh.d_raw, raw, 3 * sizeof(double), true, direct_raw, st_raw, up)); sent = true; }
+        if (upload && count) { CTX_TRY(rows(sh, k, sh.d_count, count, sizeof(int32_t), true, direct_count, st_count, up)); sent = true; }
+        if (sent) CTX_TRY(hipEventRecord(sh.uploaded, up));
+        const bool own_raw = own_sums != 0 && !raw, own_count = own_sums != 0 && !count;
+        if (own_sums == 1 && own_raw) CTX_TRY(hipMemsetAsync(sh.d_raw, 0, slab * 3 * sizeof(double), sh.compute));
+        if (own_sums == 1 && own_count) CTX_TRY(hipMemsetAsync(sh.d_count, 0, slab * sizeof(int32_t), sh.compute));
+        if ((rc = sh.job.finish(d_color, raw || own_raw ? sh.d_raw : nullptr, count || own_count ? sh.d_count : nullptr,
+                                sent ? sh.uploaded : nullptr)))
             return rc;
+        pass->ticket[(size_t)k] = sh.job.ticket;
         // results come back on the compute stream, behind the kernels
-        CTX_TRY(rows(sh, k, sh.d_color, color, sizeof(uint32_t), false, direct_color, sh.stage, sh.compute));
+        CTX_TRY(rows(sh, k, d_color, color, sizeof(uint32_t), false, direct_color, st_color, sh.compute));
         if (download && raw) CTX_TRY(rows(sh, k, sh.d_raw, raw, 3 * sizeof(double), false, direct_raw, st_raw, sh.compute));
         if (download && count) CTX_TRY(rows(sh, k, sh.d_count, count, sizeof(int32_t), false, direct_count, st_count, sh.compute));
-    }
-    // ---- wait, hand the staged rows out, collect the statistics ---------------------------------------------------
-    for (int32_t k = 0; k < G; ++k) {
-        CtxShare& sh = c->shares[(size_t)k];
-        if (!sh.active) continue;
-        DeviceGuard g(sh.device);
-        CTX_TRY(hipStreamSynchronize(sh.compute));
-        const size_t n_rows = (size_t)sh.job.part.n_rows, slab = n_rows * W;
-        auto scatter = [&](void* host, const char* stage, size_t elem) {
-            char* h = (char*)host + (size_t)k * W * elem;
-            const size_t row = W * elem, host_pitch = (size_t)G * row;
-            for (size_t r = 0; r < n_rows; ++r) std::memcpy(h + r * host_pitch, stage + r * row, row);
-        };
-        if (!direct_color) scatter(color, sh.stage, sizeof(uint32_t));
-        if (download && raw && !direct_raw) scatter(raw, sh.stage + slab * sizeof(uint32_t), 3 * sizeof(double));
-        if (download && count && !direct_count) scatter(count, sh.stage + slab * (sizeof(uint32_t) + 3 * sizeof(double)), sizeof(int32_t));
-        if ((rc = sh.job.collect(&sh.stats))) return rc;
+        CTX_TRY(hipEventRecord(sh.pass_done[buf], sh.compute));
         sh.active = false;
     }
-#undef CTX_TRY
     guard.armed = false;
     c->res_W = (int32_t)W; c->res_H = (int32_t)H; c->res_raw = raw != nullptr; c->res_count = count != nullptr;
+    return DRAY_OK;
+}
+
+// Second half: waits for the pass, hands the staged rows out, adds the shares' statistics up.
+int context_complete_locked(dray_context* c, const CtxPass& pass, uint32_t* color, double* raw, int32_t* count, dray_stats* stats) {
+    const int32_t G = (int32_t)c->shares.size();
+    const size_t W = pass.W, H = pass.H;
     if (stats) {
-        for (const CtxShare& sh : c->shares) {
-            const dray_stats& s = sh.stats;
-            stats->segments += s.segments; stats->samples += s.samples; stats->walk_steps += s.walk_steps;
-            stats->rows_rendered += s.rows_rendered;
-            stats->kernel_ms = std::fmax(stats->kernel_ms, s.kernel_ms);   // the shares run side by side
-            stats->resolve_ms = std::fmax(stats->resolve_ms, s.resolve_ms);
-            if (s.n_wide_spheres > stats->n_wide_spheres) stats->n_wide_spheres = s.n_wide_spheres;
+        std::memset(stats, 0, sizeof *stats);
+        stats->image_height = (int32_t)H;
+        stats->n_spheres = (int32_t)c->spheres.size();
+    }
+    for (int32_t k = 0; k < G; ++k) {
+        CtxShare& sh = c->shares[(size_t)k];
+        if ((size_t)k >= pass.ticket.size() || pass.ticket[(size_t)k] == 0) continue;
+        DeviceGuard g(sh.device);
+        const hipError_t e = hipEventSynchronize(sh.pass_done[pass.buf]);
+        if (e != hipSuccess) {
+            c->res_W = c->res_H = 0;
+            return hip_fail(e, "hipEventSynchronize");
         }
+        const size_t slab = share_rows(H, k, G) * W;
+        if (pass.staged_color) scatter_rows(color, pass.buf > 0 ? sh.stage_more[pass.buf - 1] : sh.stage, sizeof(uint32_t), W, H, k, G);
+        if (pass.staged_raw) scatter_rows(raw, sh.stage + slab * sizeof(uint32_t), 3 * sizeof(double), W, H, k, G);
+        if (pass.staged_count) scatter_rows(count, sh.stage + slab * (sizeof(uint32_t) + 3 * sizeof(double)), sizeof(int32_t), W, H, k, G);
+        dray_stats st{};
+        const int rc = collect_call(sh.scene, pass.ticket[(size_t)k], &st);
+        if (rc) return rc;
+        if (stats) {
+            stats->segments += st.segments; stats->samples += st.samples; stats->walk_steps += st.walk_steps;
+            stats->rows_rendered += st.rows_rendered;
+            stats->kernel_ms = std::fmax(stats->kernel_ms, st.kernel_ms);   // the shares run side by side
+            stats->resolve_ms = std::fmax(stats->resolve_ms, st.resolve_ms);
+            if (st.n_wide_spheres > stats->n_wide_spheres) stats->n_wide_spheres = st.n_wide_spheres;
+        }
+    }
+    return DRAY_OK;
+}
+#undef CTX_TRY
+
+// The whole frame into host buffers: see dray_context_render in dray.h.
+int context_render_locked(dray_context* c, const dray_camera* cam, uint32_t* color, double* raw, int32_t* count,
+                          size_t buf_len, const dray_opts* opts_in, uint32_t sync, dray_stats* stats) {
+    const auto t_begin = std::chrono::steady_clock::now();
+    CtxPass pass;
+    int rc = context_enqueue_locked(c, cam, color, raw, count, buf_len, opts_in, sync, 0, false, 0, &pass);
+    if (rc == DRAY_OK) rc = context_complete_locked(c, pass, color, raw, count, stats);
+    else if (stats) std::memset(stats, 0, sizeof *stats);
+    if (rc == DRAY_OK && stats)
+        stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    return rc;
+}
+
+// A frame's samples in passes, two passes under way at a time: see dray_context_render_progressive in dray.h.
+int context_render_progressive_locked(dray_context* c, const dray_camera* cam, uint32_t* color, double* raw, int32_t* count,
+                                      size_t buf_len, const dray_opts* opts_in, int32_t samples_per_pass,
+                                      dray_present_fn present, void* user, dray_stats* stats) {
+    const auto t_begin = std::chrono::steady_clock::now();
+    if (!camera_ok(cam) || samples_per_pass <= 0) return DRAY_ERR_INVALID_ARG;
+    dray_opts opts;
+    if (opts_in) opts = *opts_in; else dray_opts_default(&opts);
+    const int32_t total = cam->samples_per_pixel;
+    const int32_t n_pass = total <= 0 ? 1 : (total + samples_per_pass - 1) / samples_per_pass;
+    dray_stats sum{};
+    CtxPass under_way[kCtxRoutes];
+    dray_camera pass_cam[kCtxRoutes];
+    auto enqueue = [&](int32_t p) {
+        const int r = p % kCtxRoutes;
+        pass_cam[r] = *cam;
+        const int32_t first = p * samples_per_pass;
+        pass_cam[r].samples_per_pixel = total <= 0 ? total : (total - first < samples_per_pass ? total - first : samples_per_pass);
+        dray_opts o = opts;
+        o.sample_offset = opts.sample_offset + (uint32_t)first;
+        const uint32_t sync = (p == 0 ? DRAY_SYNC_UPLOAD_SUMS : 0u) | (p == n_pass - 1 ? DRAY_SYNC_DOWNLOAD_SUMS : 0u);
+        return context_enqueue_locked(c, &pass_cam[r], color, raw, count, buf_len, &o, sync, r, n_pass > 1,
+                                      n_pass > 1 ? (p == 0 ? 1 : 2) : 0, &under_way[r]);
+    };
+    // Three passes are under way at a time: while pass p's picture is handed out, pass p + 1 is on the GPU (its trace
+    // kernel holds the compute units, and pass p's small last kernel completes as that one runs out) and pass p + 2 is
+    // enqueued behind it, so that the GPU does not wait for this thread between passes.
+    int rc = DRAY_OK;
+    for (int32_t p = 0; rc == DRAY_OK && p < n_pass && p < kCtxRoutes; ++p) rc = enqueue(p);
+    for (int32_t p = 0; rc == DRAY_OK && p < n_pass; ++p) {
+        dray_stats st{};
+        rc = context_complete_locked(c, under_way[p % kCtxRoutes], color, raw, count, &st);
+        if (rc) break;
+        if (p == 0) sum = st;
+        else {
+            sum.segments += st.segments; sum.samples += st.samples; sum.walk_steps += st.walk_steps;
+            sum.kernel_ms += st.kernel_ms; sum.resolve_ms += st.resolve_ms;
+        }
+        const int32_t done = (p + 1) * samples_per_pass < total ? (p + 1) * samples_per_pass : total;
+        if (present && total > 0) present(user, p, done); // camera.rs:217: no samples, nothing to show
+        if (p + kCtxRoutes < n_pass) rc = enqueue(p + kCtxRoutes); // its colour route is the one just handed out
+    }
+    if (rc != DRAY_OK) { // whatever is still under way must not outlive the buffers it writes
+        for (CtxShare& sh : c->shares) {
+            DeviceGuard g(sh.device);
+            (void)hipStreamSynchronize(sh.compute);
+        }
+        c->res_W = c->res_H = 0;
+        return rc;
+    }
+    if (stats) {
+        *stats = sum;
         stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     }
     return DRAY_OK;
@@ -1637,6 +1781,18 @@ int dray_context_render(dray_context* ctx, const dray_camera* cam, uint32_t* col
         if (!ctx) return DRAY_ERR_INVALID_ARG;
         std::lock_guard<std::mutex> lock(ctx->mu);
         return context_render_locked(ctx, cam, color, raw, count, buf_len, opts, sync, stats);
+    } catch (...) {
+        return DRAY_ERR_INTERNAL;
+    }
+}
+
+int dray_context_render_progressive(dray_context* ctx, const dray_camera* cam, uint32_t* color, double* raw, int32_t* count,
+                                    size_t buf_len, const dray_opts* opts, int32_t samples_per_pass, dray_present_fn present,
+                                    void* user, dray_stats* stats) {
+    try {
+        if (!ctx) return DRAY_ERR_INVALID_ARG;
+        std::lock_guard<std::mutex> lock(ctx->mu);
+        return context_render_progressive_locked(ctx, cam, color, raw, count, buf_len, opts, samples_per_pass, present, user, stats);
     } catch (...) {
         return DRAY_ERR_INTERNAL;
     }

@@ -211,6 +211,27 @@ class RenderContext:
             raw_buffer.ctypes.data if raw_buffer is not None else None,
             count_buffer.ctypes.data if count_buffer is not None else None, buf_len, C.byref(opts), sync, C.byref(stats))
 
+    def render_progressive(self, pod, color_buffer, raw_buffer, count_buffer, buf_len, opts, samples_per_pass, present, stats):
+        """dray_context_render_progressive: ``present(pass_index, samples_done)`` (or None) is called after every pass."""
+        failure = []
+
+        def trampoline(_user, index, done):   # an exception must not unwind through the C frames
+            try:
+                if present is not None and not failure:
+                    present(index, done)
+            except BaseException as e:   # noqa: BLE001 -- re-raised below
+                failure.append(e)
+
+        cb = _ffi.PRESENT_FN(trampoline)
+        rc = _ffi.lib().dray_context_render_progressive(
+            self.handle, C.byref(pod), color_buffer.ctypes.data,
+            raw_buffer.ctypes.data if raw_buffer is not None else None,
+            count_buffer.ctypes.data if count_buffer is not None else None, buf_len, C.byref(opts), int(samples_per_pass),
+            cb, None, C.byref(stats))
+        if failure:
+            raise failure[0]
+        return rc
+
     def close(self):
         if self._h is not None:
             _ffi.lib().dray_context_destroy(self._h)
@@ -326,6 +347,19 @@ class Camera:
             if opts_row_partition(opts):
                 raise DrayError(_ffi.ERR_INVALID_ARG, "a context makes the row partition itself")
             ctx.set_scene(spheres)   # a no-op when the list is the one the context holds
+            if per_pass < total:
+                # the passes of one call, two under way at a time: the sums go up before the first and come back after
+                # the last, in between only the colours move, and the window is refreshed while the next pass renders
+                st = _ffi.Stats()
+                W, H = self.image_width, self.image_height
+
+                def show(_index, _done):
+                    if window is not None:
+                        window.update_with_buffer(color_buffer, W, H)
+
+                _ffi.check(ctx.render_progressive(pod, color_buffer, raw_buffer, count_buffer, buf_len, opts, per_pass, show, st))
+                self.last_stats = st
+                return None
         while True:  # at least one call, so that a camera of 0 samples fails (or not) the way one call does
             pod.samples_per_pixel = min(per_pass, total - done) if total > 0 else total
             opts.sample_offset = first_sample + done

@@ -240,6 +240,19 @@ void dray_context_destroy(dray_context* ctx);
 int dray_context_set_scene(dray_context* ctx, const dray_sphere* spheres, size_t n_spheres);
 int dray_context_render(dray_context* ctx, const dray_camera* cam, uint32_t* color, double* raw, int32_t* count,
                         size_t buf_len, const dray_opts* opts, uint32_t sync, dray_stats* stats);
+/* A frame's samples in passes with the picture handed out after each: what Camera::render does when it presents the
+ * window while it renders (colors.rs:44 presents after every sample of every pixel; here after every pass of
+ * `samples_per_pass` samples per pixel, the last pass taking what is left of cam->samples_per_pixel).  The running sums
+ * go up before the first pass and come back after the last, as with dray_context_render(UPLOAD | DOWNLOAD) in one call,
+ * and the three buffers end up bit for bit as after that call; opts->sample_offset is advanced pass by pass.  After
+ * each pass, once its colours are in `color`, `present(user, pass, samples_done)` is called on the calling thread (NULL:
+ * no call); the next pass is already rendering by then and the one after it is enqueued (three passes are under way
+ * at a time), so what `present` takes does not hold the GPU up.  `color` must not be touched outside `present` while the call runs.  stats: segments,
+ * samples and kernel times added up over the passes.  No counterpart in the reference beyond that per-sample present. */
+typedef void (*dray_present_fn)(void* user, int32_t pass, int32_t samples_done);
+int dray_context_render_progressive(dray_context* ctx, const dray_camera* cam, uint32_t* color, double* raw, int32_t* count,
+                                    size_t buf_len, const dray_opts* opts, int32_t samples_per_pass, dray_present_fn present,
+                                    void* user, dray_stats* stats);
 int dray_context_host_alloc(dray_context* ctx, size_t bytes, void** out);
 int dray_context_pin(dray_context* ctx, void* host, size_t bytes);
 void dray_context_unpin(dray_context* ctx);

@@ -17,6 +17,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <exception>
 #include <memory>
 #include <random>
 #include <stdexcept>
@@ -276,6 +277,34 @@ class Camera {
         int32_t done = 0;
         const dray_sphere* sp = spheres.empty() ? nullptr : spheres.data();
         if (context) check(dray_context_set_scene(context->handle(), sp, spheres.size()), "Camera::render"); // a no-op for the list it holds
+        if (context && per_pass < total) {
+            // the passes of one call, two under way at a time: the sums go up before the first and come back after
+            // the last, and `present` runs while the next pass renders
+            struct Show {
+                Present* present;
+                std::vector<uint32_t>* color;
+                int32_t width, height;
+                std::exception_ptr failed;
+                static void call(void* user, int32_t, int32_t) noexcept {
+                    Show* s = (Show*)user;
+                    if (s->failed) return;
+                    try {
+                        (*s->present)(*s->color, s->width, s->height);
+                    } catch (...) { // must not unwind through the C frames: thrown again below
+                        s->failed = std::current_exception();
+                    }
+                }
+            } show{&present, &color_buffer, image_width, image_height(), nullptr};
+            dray_stats st{};
+            check(dray_context_render_progressive(context->handle(), &c, color_buffer.data(),
+                                                  raw_buffer.empty() ? nullptr : raw_buffer.data(),
+                                                  count_buffer.empty() ? nullptr : count_buffer.data(), buf_len, &o, per_pass,
+                                                  &Show::call, &show, &st),
+                  "Camera::render");
+            if (show.failed) std::rethrow_exception(show.failed);
+            last_stats = st;
+            return;
+        }
         do { // at least one call, so that a camera of 0 samples fails (or not) the way one call does
             c.samples_per_pixel = total > 0 && total - done < per_pass ? total - done : per_pass;
             o.sample_offset = opts.sample_offset + (uint32_t)done;

@@ -187,6 +187,9 @@ pub struct dray_grid_info {
 }
 
 // ---- functions --------------------------------------------------------------------------------------------
+/// `dray_present_fn`: called after every pass of `dray_context_render_progressive`, on the calling thread.
+pub type dray_present_fn = Option<unsafe extern "C" fn(user: *mut c_void, pass: i32, samples_done: i32)>;
+
 extern "C" {
     pub fn dray_version() -> *const c_char;
     pub fn dray_strerror(status: c_int) -> *const c_char;
@@ -234,6 +237,19 @@ extern "C" {
         buf_len: usize,
         opts: *const dray_opts,
         sync: u32,
+        stats: *mut dray_stats,
+    ) -> c_int;
+    pub fn dray_context_render_progressive(
+        ctx: *mut dray_context,
+        cam: *const dray_camera,
+        color: *mut u32,
+        raw: *mut f64,
+        count: *mut i32,
+        buf_len: usize,
+        opts: *const dray_opts,
+        samples_per_pass: i32,
+        present: dray_present_fn,
+        user: *mut c_void,
         stats: *mut dray_stats,
     ) -> c_int;
     pub fn dray_context_host_alloc(ctx: *mut dray_context, bytes: usize, out: *mut *mut c_void) -> c_int;

@@ -42,7 +42,7 @@ pub fn render(
         return Err(Error::new(ErrorKind::InvalidInput, "buffers shorter than image_width * image_height"));
     }
 
-    let mut cam = sys::dray_camera {
+    let cam = sys::dray_camera {
         aspect_ratio: self.aspect_ratio,
         image_width: self.image_width,
         samples_per_pixel: self.samples_per_pixel,
@@ -88,27 +88,33 @@ pub fn render(
     }
 
     // Each call continues the Philox streams of the samples the buffers already hold.
-    let first_sample = count_buffer.first().copied().unwrap_or(0).max(0) as u32;
+    opts.sample_offset = count_buffer.first().copied().unwrap_or(0).max(0) as u32;
     let total = self.samples_per_pixel;
-    let per_pass = if SAMPLES_PER_PASS > 0 && SAMPLES_PER_PASS < total { SAMPLES_PER_PASS } else { total };
-    let mut done = 0;
-    loop {
-        cam.samples_per_pixel = if total > 0 { per_pass.min(total - done) } else { total };
-        opts.sample_offset = first_sample + done as u32;
-        let last = total <= 0 || done + cam.samples_per_pixel >= total;
-        let sync = (if done == 0 { sys::DRAY_SYNC_UPLOAD_SUMS } else { 0 }) | (if last { sys::DRAY_SYNC_DOWNLOAD_SUMS } else { 0 });
-        let rc = unsafe {
-            sys::dray_context_render(ctx, &cam, color_buffer.as_mut_ptr(), raw.as_mut_ptr(), count_buffer.as_mut_ptr(), used,
-                                     &opts, sync, std::ptr::null_mut())
-        };
-        if rc != sys::DRAY_OK {
-            return Err(fail(rc));
-        }
-        let _ = window.update_with_buffer(&color_buffer, width, height); // colors.rs:44, once per pass
-        done += cam.samples_per_pixel;
-        if done >= total {
-            break;
-        }
+    let per_pass = if SAMPLES_PER_PASS > 0 && SAMPLES_PER_PASS < total { SAMPLES_PER_PASS } else { total.max(1) };
+
+    // The window is presented after every pass (colors.rs:44 presents after every pixel sample) from a callback the
+    // library makes on this thread once the pass's colours are in `color_buffer`; the next pass is rendering by then.
+    // The running sums go up before the first pass and come back after the last (dray_context_render with
+    // DRAY_SYNC_UPLOAD_SUMS | DRAY_SYNC_DOWNLOAD_SUMS is the same frame in one pass, without the callback).
+    struct Show<'a> {
+        window: &'a mut Window,
+        color: *const u32,
+        len: usize,
+        width: usize,
+        height: usize,
+    }
+    unsafe extern "C" fn show(user: *mut std::ffi::c_void, _pass: i32, _samples_done: i32) {
+        let s = &mut *(user as *mut Show);
+        let _ = s.window.update_with_buffer(std::slice::from_raw_parts(s.color, s.len), s.width, s.height);
+    }
+    let mut user = Show { window, color: color_buffer.as_ptr(), len: color_buffer.len(), width, height };
+    let rc = unsafe {
+        sys::dray_context_render_progressive(ctx, &cam, color_buffer.as_mut_ptr(), raw.as_mut_ptr(), count_buffer.as_mut_ptr(),
+                                             used, &opts, per_pass, Some(show), &mut user as *mut Show as *mut std::ffi::c_void,
+                                             std::ptr::null_mut())
+    };
+    if rc != sys::DRAY_OK {
+        return Err(fail(rc));
     }
 
     for (v, c) in raw_buffer.iter_mut().zip(raw.chunks_exact(3)) {

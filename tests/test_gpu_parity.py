@@ -624,6 +624,62 @@ def test_progressive_passes_equal_one_pass(dray, gpu):
             assert r[3] == results[0][3]
 
 
+def test_context_progressive_presents_every_pass(dray, gpu):
+    """dray_context_render_progressive: the passes of one call, two under way at a time.  The picture presented after
+    pass p is the picture of the first p + 1 passes' samples (the same as a render of that many samples), the buffers
+    end up as after one pass of all the samples, the statistics are the passes' totals, an exception in the window's
+    update comes back to the caller, and a pass size of 0 is refused."""
+    from dray_amd import _ffi
+
+    class Window:
+        def __init__(self, fail_at=None):
+            self.frames, self.fail_at = [], fail_at
+
+        def update_with_buffer(self, buf, w, h):
+            if self.fail_at is not None and len(self.frames) == self.fail_at:
+                raise KeyError("window closed")
+            self.frames.append(buf[:w * h].copy())
+
+    world = dray.scene_final(3)
+    W = 72
+    for mode, devices in ((dray.MODE_F32, [0]), (dray.MODE_F32, [0, 0, 0]), (dray.MODE_F64, [0, 0])):
+        ctx = dray.RenderContext(devices)
+        cam = dray.camera_final(width=W, spp=11, depth=8)
+        cam.mode, cam.seed, cam.context, cam.samples_per_pass = mode, 9, ctx, 3       # passes of 3, 3, 3, 2
+        color, raw, count = np.zeros(W * W, np.uint32), np.zeros((W * W, 3)), np.zeros(W * W, np.int32)
+        win = Window()
+        cam.render(world, win, color, raw, count)
+        H = cam.image_height
+        assert len(win.frames) == 4 and (win.frames[-1] == color[:W * H]).all()
+        total = cam.last_stats
+        assert total.samples == 11 * W * H and total.rows_rendered == H
+        for k, upto in enumerate((3, 6, 9, 11)):
+            one = dray.camera_final(width=W, spp=upto, depth=8)
+            one.mode, one.seed = mode, 9
+            c1, r1, n1 = np.zeros(W * W, np.uint32), np.zeros((W * W, 3)), np.zeros(W * W, np.int32)
+            one.render(world, None, c1, r1, n1)
+            assert (win.frames[k] == c1[:W * H]).all(), (mode, devices, k)
+        assert (c1 == color).all() and (r1 == raw).all() and (n1 == count).all()
+        assert total.segments == one.last_stats.segments
+        # a second progressive call continues the first (colors.rs:38-39), with the sums it finds in the buffers
+        cam.render(world, None, color, raw, count, sample_offset=11)
+        two = dray.camera_final(width=W, spp=22, depth=8)
+        two.mode, two.seed = mode, 9
+        c2, r2, n2 = np.zeros(W * W, np.uint32), np.zeros((W * W, 3)), np.zeros(W * W, np.int32)
+        two.render(world, None, c2, r2, n2)
+        assert (c2 == color).all() and (r2 == raw).all() and (n2 == count).all()
+        # the window fails at its second update: the error comes back, the context stays usable
+        with pytest.raises(KeyError):
+            cam.render(world, Window(fail_at=1), np.zeros(W * W, np.uint32), None, None)
+        again = np.zeros(W * W, np.uint32)
+        cam.render(world, None, again, None, None)
+        assert (again[:W * H] == win.frames[-1]).all()
+        st = _ffi.Stats()
+        assert ctx.render_progressive(cam.pod(), color, raw, count, color.size, cam.opts(), 0, None, st) == _ffi.ERR_INVALID_ARG
+        assert ctx.render_progressive(cam.pod(), color, raw, count, 10, cam.opts(), 3, None, st) == _ffi.ERR_BUFFER_TOO_SMALL
+        ctx.close()
+
+
 def test_scan_variants_agree_on_random_scenes(dray, gpu):
     """tools/fuzz_scans.py's generator: 160 random scenes (clouds, flat and line layouts, clusters, shells; scales from
     0.1 to 100, offsets up to 30 scene sizes; up to 11 outsized spheres, a sphere routed to the f64 test that encloses

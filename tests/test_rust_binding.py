@@ -212,9 +212,8 @@ def test_crate_files_and_flattener_names():
         assert re.search(r"type %s\s*=" % assoc, code), assoc
     render = strip_rust_comments(open(RENDER_RS).read())
     assert '#[cfg(feature = "hip")]' in render and "update_with_buffer" in render
-    # the render goes through a context: the sums go up with the first pass and come back with the last
-    for name in ("dray_context_create", "dray_context_set_scene", "dray_context_render", "DRAY_SYNC_UPLOAD_SUMS",
-                 "DRAY_SYNC_DOWNLOAD_SUMS"):
+    # the render goes through a context, in passes, the window presented from the library's callback after each
+    for name in ("dray_context_create", "dray_context_set_scene", "dray_context_render_progressive", 'extern "C" fn show'):
         assert name in render, name
     sig = re.sub(r"\s+", " ", render)
     assert ("pub fn render( &mut self, world: &dyn Hittable, window: &mut Window, color_buffer: &mut Vec<u32>, "
