@@ -247,8 +247,9 @@ int dray_context_render(dray_context* ctx, const dray_camera* cam, uint32_t* col
  * and the three buffers end up bit for bit as after that call; opts->sample_offset is advanced pass by pass.  After
  * each pass, once its colours are in `color`, `present(user, pass, samples_done)` is called on the calling thread (NULL:
  * no call); the next pass is already rendering by then and the one after it is enqueued (three passes are under way
- * at a time), so what `present` takes does not hold the GPU up.  `color` must not be touched outside `present` while the call runs.  stats: segments,
- * samples and kernel times added up over the passes.  No counterpart in the reference beyond that per-sample present. */
+ * at a time), so what `present` takes does not hold the GPU up.  `color` must not be touched outside `present` while
+ * the call runs, and `present` must not call into the same context (the call holds it).  stats: segments, samples
+ * and kernel times added up over the passes.  No counterpart in the reference beyond that per-sample present. */
 typedef void (*dray_present_fn)(void* user, int32_t pass, int32_t samples_done);
 int dray_context_render_progressive(dray_context* ctx, const dray_camera* cam, uint32_t* color, double* raw, int32_t* count,
                                     size_t buf_len, const dray_opts* opts, int32_t samples_per_pass, dray_present_fn present,
