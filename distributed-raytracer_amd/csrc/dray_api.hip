@@ -28,6 +28,7 @@ constexpr int kCallSlots = 16;
 struct CallSlot {
     DeviceCounters* d_counters = nullptr; // this slot's counters (or, for the allocation-free call, the static workspace's)
     DeviceCounters* own_counters = nullptr;
+    DeviceCounters* h_counters = nullptr; // what the call counted, in page-locked host memory the device writes to
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr}; // trace begins, trace ends, results are in the caller's buffers
     uint64_t ticket = 0;                            // number of the call that holds the slot (1, 2, ...); 0: none yet
     dray_stats base{};                              // the fields known on the host
@@ -53,7 +54,7 @@ struct dray_scene {
     uint64_t calls = 0;                        // calls that have taken a slot
     TraceSpace space[2];
     int next_space = 0;
-    hipStream_t stats_stream = nullptr;        // copies of the counters to the host
+    DeviceCounters* h_counter_block = nullptr; // the slots' host-side counters
     void* d_rings = nullptr;               // the f64 stream kernel's rings of finished samples (one per resident wave)
     size_t rings_bytes = 0;
     // Calls on one scene take turns on the host (`mu`, for the length of the enqueueing), and a call enqueued on
@@ -63,6 +64,21 @@ struct dray_scene {
     hipStream_t last_stream = nullptr;
     hipEvent_t last_done = nullptr;
 };
+
+// The last kernel of a call: the counters go to the slot's place in page-locked host memory, where collect_call reads
+// them once the call's last event has come.
+__global__ void counters_to_host_kernel(const DeviceCounters* __restrict__ d, DeviceCounters* __restrict__ h) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        h->segments = d->segments;
+        h->samples = d->samples;
+        h->next_item = d->next_item;
+        h->walk_steps = d->walk_steps;
+    }
+}
+static hipError_t counters_to_host(const CallSlot* slot, hipStream_t stream) {
+    hipLaunchKernelGGL(counters_to_host_kernel, dim3(1), dim3(64), 0, stream, slot->d_counters, slot->h_counters);
+    return hipGetLastError();
+}
 
 // Workspace of the allocation-free entry point (dray_render_device_noalloc): the f32 kernel's fixed-point sums
 // and the counters of one render, in device memory that belongs to the code object -- no hipMalloc on any call.
@@ -206,7 +222,7 @@ void scene_free(dray_scene* s) {
         (void)hipFree(t.d_accum);
         if (t.side) (void)hipStreamDestroy(t.side);
     }
-    if (s->stats_stream) (void)hipStreamDestroy(s->stats_stream);
+    if (s->h_counter_block) (void)hipHostFree(s->h_counter_block);
     for (CallSlot& c : s->slots)
         for (auto& e : c.ev)
             if (e) (void)hipEventDestroy(e);
@@ -628,14 +644,15 @@ int scene_create_impl(const dray_sphere* sp, size_t n, int32_t device, dray_scen
     constexpr size_t kCounterStride = 256; // counters of calls in flight at once do not share a cache line
     static_assert(sizeof(DeviceCounters) <= kCounterStride, "counters outgrew their stride");
     hipError_t e = hipMalloc((void**)&s->d_counter_block, kCallSlots * kCounterStride);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&s->h_counter_block, kCallSlots * sizeof(DeviceCounters), hipHostMallocDefault);
     for (int q = 0; q < kCallSlots && e == hipSuccess; ++q) {
         s->slots[q].own_counters = (DeviceCounters*)((char*)s->d_counter_block + q * kCounterStride);
+        s->slots[q].h_counters = s->h_counter_block + q;
         for (auto& ev : s->slots[q].ev)
             if (e == hipSuccess) e = hipEventCreate(&ev);
     }
     for (TraceSpace& t : s->space)
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&t.side, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->stats_stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         scene_free(s);
         return hip_fail(e, "scene workspace");
@@ -696,11 +713,9 @@ int collect_call(dray_scene* scene, uint64_t ticket, dray_stats* stats) {
         return DRAY_ERR_INVALID_ARG;
     }
     HIP_TRY(hipEventSynchronize(slot->ev[2]));
-    // (on a stream of the scene's own: a copy on the default stream would wait for everything enqueued there since,
-    // the renders that came after this one among it)
-    DeviceCounters hc{};
-    HIP_TRY(hipMemcpyAsync(&hc, slot->d_counters, sizeof hc, hipMemcpyDeviceToHost, scene->stats_stream));
-    HIP_TRY(hipStreamSynchronize(scene->stats_stream));
+    // (the call's last kernel has put the counters into host memory: no copy, which on the default stream would wait
+    // for every render enqueued there since, and no stream of the scene's own for it -- a process has few hardware queues)
+    const DeviceCounters hc = *slot->h_counters;
     float k_ms = 0.f, r_ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&k_ms, slot->ev[0], slot->ev[1]));
     HIP_TRY(hipEventElapsedTime(&r_ms, slot->ev[1], slot->ev[2]));
@@ -847,6 +862,7 @@ struct RenderJob {
         if (inputs_ready) HIP_TRY(hipStreamWaitEvent(stream, inputs_ready, 0));
         if (opts.mode == DRAY_MODE_F32) {
             HIP_TRY(launch_resolve_f32(make_cam<float>(*cam, dv), part, d_accum, d_color, d_raw, d_count, stream));
+            HIP_TRY(counters_to_host(slot, stream));
             HIP_TRY(hipEventRecord(slot->ev[2], stream));
             if (space) space->free_after = slot->ev[2];
         } else {
@@ -879,6 +895,7 @@ struct RenderJob {
                 HIP_TRY(launch_render_ref_f32(make_cam<float>(*cam, dv), scene->dev, part, key, opts.flags, d_color, d_raw,
                                               d_count, d_counters, stream));
             HIP_TRY(hipEventRecord(slot->ev[1], stream));
+            HIP_TRY(counters_to_host(slot, stream));
             HIP_TRY(hipEventRecord(slot->ev[2], stream));
         }
         scene->last_done = slot->ev[2];
@@ -1571,6 +1588,7 @@ int path_step_device_impl(dray_scene* scene, int32_t image_width, dray_path_entr
         HIP_TRY(launch_path_step(scene->dev, key, image_width, opts.variant != DRAY_SCAN_SCALAR, d_entries, n,
                                  slot->d_counters, stream));
         HIP_TRY(hipEventRecord(slot->ev[1], stream));
+        HIP_TRY(counters_to_host(slot, stream));
         HIP_TRY(hipEventRecord(slot->ev[2], stream));
         scene->last_done = slot->ev[2];
         if (ticket) *ticket = slot->ticket;
