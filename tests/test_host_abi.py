@@ -295,6 +295,9 @@ def test_entry_points_reject_bad_arguments(dray):
     assert L.dray_render_device_async(C.byref(cam), None, color.ctypes.data, None, None, color.size, C.byref(opts), None,
                                       C.byref(ticket)) == INV and ticket.value == 0
     assert L.dray_scene_collect(None, 1, C.byref(_ffi.Stats())) == INV
+    assert L.dray_context_render(None, C.byref(cam), color.ctypes.data, None, None, color.size, C.byref(opts), 3, None) == INV
+    assert L.dray_context_render_progressive(None, C.byref(cam), color.ctypes.data, None, None, color.size, C.byref(opts), 5,
+                                             _ffi.PRESENT_FN(), None, None) == INV
     assert L.dray_camera_rays(None, None, 1, None, None) == INV
     assert L.dray_path_step(None, 10, None, 1, None, None) == INV
     assert L.dray_camera_rays_device(None, None, 1, None, None, None) == INV
