@@ -142,6 +142,7 @@ struct F64StreamPlan {
     int32_t grid, block;   // resident blocks of the persistent launch
     size_t ring_bytes;     // one ring per wave of the launch
     uint32_t chunk_pixels; // consecutive pixels a wave takes from the queue at a time
+    size_t lds_bytes;      // dynamic LDS of the launch: the staged copy of the grid (0: the tables are read from memory)
 };
 // false: this frame or scene is not for the stream kernel (no grid over the scene, no samples)
 bool plan_render_f64_stream(const CamDev<double>& cam, const Partition& part, const SceneDev& scene, int device,

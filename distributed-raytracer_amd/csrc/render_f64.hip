@@ -27,6 +27,7 @@
 // the scan of the whole list, as there.
 #pragma clang fp contract(off)
 
+#include <cstdlib>
 #include <mutex>
 
 #include "ref_device.h"
@@ -169,7 +170,15 @@ struct F64Args {
     DeviceCounters* counters;
     RingEntry* rings;
     uint32_t chunk_pixels;
+    int32_t n_cells, n_entries; // the grid's tables (the kernel that stages a copy of the grid in LDS)
 };
+
+// The copy of the grid a workgroup of the LDS kernel stages at its entry, so compact that four workgroups' copies fit
+// a compute unit: the spheres' rows (cx, cy, cz, radius: the f64 geometry table as it is, by list position), then a
+// word per cell -- first entry (12 bits) | entry count (4 bits) | list position of the first entry's sphere (16 bits)
+// --, then the entries as 16-bit list positions.  A lane entering a cell has its first sphere from the cell's word, a
+// lane staying in its cell reads the entry table: two dependent reads per step, both from LDS.
+constexpr uint32_t kLds64BeginBits = 12u, kLds64CountBits = 4u;
 
 // Hides where a pointer came from, so that reads through it are not moved across this point.
 template <typename T>
@@ -179,10 +188,38 @@ __device__ __forceinline__ const DRAY_CONSTANT T* opaque(const DRAY_CONSTANT T* 
     return (const DRAY_CONSTANT T*)v;
 }
 
-template <bool ITERATIVE>
+template <bool ITERATIVE, bool LDSGRID>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DRAY_F64_WAVES_PER_EU, DRAY_F64_WAVES_PER_EU)))
 void render_f64_stream_kernel(F64Args) {
     const DRAY_CONSTANT F64Args* ka = (const DRAY_CONSTANT F64Args*)__builtin_amdgcn_kernarg_segment_ptr();
+    extern __shared__ double lds_geom[]; // LDSGRID: rows of four doubles by list position, then the cell words, then the entries
+    if constexpr (LDSGRID) {
+        const int32_t n4 = 4 * ka->n, n_cells = ka->n_cells, n_entries = ka->n_entries;
+        const double* geom = ka->geom;
+        const uint2* cells = ka->rg.grid.cells;
+        const int32_t* entry_index = ka->rg.entry_index;
+        uint32_t* lds_cells = (uint32_t*)(lds_geom + n4);
+        uint16_t* lds_entries = (uint16_t*)(lds_cells + n_cells);
+        for (int32_t k = threadIdx.x; k < n4; k += blockDim.x) lds_geom[k] = geom[k];
+        for (int32_t k = threadIdx.x; k < n_cells; k += blockDim.x) {
+            const uint2 rec = cells[k];
+            const uint32_t first = rec.y != 0u ? (uint32_t)entry_index[rec.x] : 0u;
+            lds_cells[k] = rec.x | (rec.y << kLds64BeginBits) | (first << (kLds64BeginBits + kLds64CountBits));
+        }
+        for (int32_t k = threadIdx.x; k < n_entries; k += blockDim.x) lds_entries[k] = (uint16_t)entry_index[k];
+        __syncthreads(); // the only block-wide wait: once, before any work is drawn
+    }
+    // the cell's record: first entry, entry count, and (LDSGRID) the first entry's sphere
+    auto cell_of = [&](size_t ci, uint32_t& first_sphere) -> uint2 {
+        if constexpr (LDSGRID) {
+            const uint32_t rec = ((const uint32_t*)(lds_geom + 4 * ka->n))[ci];
+            first_sphere = rec >> (kLds64BeginBits + kLds64CountBits);
+            return make_uint2(rec & ((1u << kLds64BeginBits) - 1u), (rec >> kLds64BeginBits) & ((1u << kLds64CountBits) - 1u));
+        } else {
+            first_sphere = 0u;
+            return ka->rg.grid.cells[ci];
+        }
+    };
     __shared__ uint4 lds_req[4][64];           // coop_draw64: streams handed to server lanes, one set of slots per wave
     __shared__ uint32_t lds_fifo[4][kFifoSlots]; // first pixel of the chunks the wave has grabbed, oldest first
     __shared__ double lds_stage[4][64][3];       // the colours of the samples being retired
@@ -241,6 +278,8 @@ void render_f64_stream_kernel(F64Args) {
                 F64_COUNT(18, 1);                              // walk steps
                 F64_COUNT(19, __popcll(__ballot(walking)));    // lanes walking at them
                 if (walking) {
+                    uint32_t sphere = 0u; // LDSGRID: list position of the sphere this step tests
+                    bool entered = false;
                     if (wk.e == wk.e_end) { // this cell is done: stop, or step into the next one
                         const double tx = (double)wk.c[0] * wk.A[0] + wk.B[0], ty = (double)wk.c[1] * wk.A[1] + wk.B[1],
                                      tz = (double)wk.c[2] * wk.A[2] + wk.B[2];
@@ -261,11 +300,20 @@ void render_f64_stream_kernel(F64Args) {
                             go = false;
                         }
                         walking = go;
-                        const uint2 cellrec = ka->rg.grid.cells[go ? ((size_t)wk.c[2] * ka->rg.grid.n[1] + wk.c[1]) * ka->rg.grid.n[0] + wk.c[0] : 0];
+                        const uint2 cellrec = cell_of(go ? ((size_t)wk.c[2] * ka->rg.grid.n[1] + wk.c[1]) * ka->rg.grid.n[0] + wk.c[0] : 0, sphere);
                         wk.e = cellrec.x;
                         wk.e_end = go ? cellrec.x + cellrec.y : cellrec.x;
+                        entered = true;
                     }
-                    if (wk.e != wk.e_end) {
+                    if constexpr (LDSGRID) {
+                        if (!entered && wk.e != wk.e_end) // (beside the other lanes' cell read: the two do not depend on one another)
+                            sphere = ((const uint16_t*)((const uint32_t*)(lds_geom + 4 * ka->n) + ka->n_cells))[wk.e];
+                        if (wk.e != wk.e_end) {
+                            const double* eg = lds_geom + 4 * (size_t)sphere;
+                            test64(V3<double>{eg[0], eg[1], eg[2]}, eg[3], (int32_t)sphere, ro, rd, wk);
+                            ++wk.e;
+                        }
+                    } else if (wk.e != wk.e_end) {
                         const double* eg = ka->rg.entry_geom64 + 4 * (size_t)wk.e;
                         test64(V3<double>{eg[0], eg[1], eg[2]}, eg[3], ka->rg.entry_index[wk.e], ro, rd, wk);
                         ++wk.e;
@@ -567,7 +615,8 @@ void render_f64_stream_kernel(F64Args) {
                             const double at = floor((o[a] + d[a] * t_in - (double)ka->rg.grid.lo[a]) * (double)ka->rg.grid.inv_cell[a]);
                             wk.c[a] = (int32_t)fmin(fmax(at, 0.), (double)(ka->rg.grid.n[a] - 1));
                         }
-                        const uint2 cellrec = ka->rg.grid.cells[((size_t)wk.c[2] * ka->rg.grid.n[1] + wk.c[1]) * ka->rg.grid.n[0] + wk.c[0]];
+                        uint32_t unused;
+                        const uint2 cellrec = cell_of(((size_t)wk.c[2] * ka->rg.grid.n[1] + wk.c[1]) * ka->rg.grid.n[0] + wk.c[0], unused);
                         wk.e = cellrec.x;
                         wk.e_end = cellrec.x + cellrec.y;
                         walking = true;
@@ -610,13 +659,27 @@ bool plan_render_f64_stream(const CamDev<double>& cam, const Partition& part, co
         if (f.cus == 0) {
             int v = 0;
             f.cus = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && v > 0) ? v : 256;
-            f.occ = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, render_f64_stream_kernel<false>, 256, 0) == hipSuccess && v > 0) ? v : 2;
+            f.occ = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, render_f64_stream_kernel<false, false>, 256, 0) == hipSuccess && v > 0) ? v : 2;
         }
         cus = f.cus;
         occ = f.occ;
     }
     plan->block = 256;
     plan->grid = cus * occ;
+    // the compact copy of the grid in LDS, where as many workgroups as without it fit a compute unit with theirs and the
+    // packed fields hold the grid's numbers (DRAY_GRID_LDS=0: the tables are read from memory; tests, tuning runs)
+    plan->lds_bytes = 0;
+    {
+        const size_t n_cells = (size_t)scene.grid.n[0] * (size_t)scene.grid.n[1] * (size_t)scene.grid.n[2];
+        const size_t bytes = (size_t)scene.n * 32u + n_cells * 4u + ((scene.grid_entries * 2u + 15u) & ~(size_t)15u);
+        const char* env = std::getenv("DRAY_GRID_LDS");
+        int occ_lds = 0;
+        if (!(env && env[0] == '0') && scene.n_boxes == 0 && scene.n <= 65535 && scene.grid_entries < (1u << kLds64BeginBits) &&
+            scene.grid_max_cell_entries < (1u << kLds64CountBits) && bytes <= 48 * 1024 &&
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_lds, render_f64_stream_kernel<false, true>, 256, bytes) == hipSuccess &&
+            occ_lds >= occ)
+            plan->lds_bytes = bytes;
+    }
     // a chunk holds at least 256 samples: one returning atomic per chunk on the queue's counter, which serves
     // some 80 M of them per second
     const uint32_t spp = (uint32_t)cam.spp;
@@ -640,11 +703,14 @@ hipError_t launch_render_f64_stream(const CamDev<double>& cam, const SceneDev& s
     args.part = part; args.key = key;
     args.color = d_color; args.raw = d_raw; args.count = d_count; args.counters = d_counters;
     args.rings = (RingEntry*)rings; args.chunk_pixels = plan.chunk_pixels;
+    args.n_cells = scene.grid.n[0] * scene.grid.n[1] * scene.grid.n[2];
+    args.n_entries = (int32_t)scene.grid_entries;
     auto launch = [&](auto kernel) {
-        hipLaunchKernelGGL(kernel, dim3((unsigned)plan.grid), dim3(plan.block), 0, stream, args);
+        hipLaunchKernelGGL(kernel, dim3((unsigned)plan.grid), dim3(plan.block), plan.lds_bytes, stream, args);
     };
-    if (flags & DRAY_FLAG_ITERATIVE_PRODUCT) launch(render_f64_stream_kernel<true>);
-    else launch(render_f64_stream_kernel<false>);
+    const bool iterative = (flags & DRAY_FLAG_ITERATIVE_PRODUCT) != 0;
+    if (plan.lds_bytes != 0) iterative ? launch(render_f64_stream_kernel<true, true>) : launch(render_f64_stream_kernel<false, true>);
+    else iterative ? launch(render_f64_stream_kernel<true, false>) : launch(render_f64_stream_kernel<false, false>);
     return hipGetLastError();
 }
 

@@ -52,8 +52,9 @@ def render_gpu(dray, gpu, spheres, cam, **opts):
 
 
 def render_gpu_grid_from_memory(dray, gpu, spheres, cam, **opts):
-    """The f32 grid scan with the grid's tables read from memory even where they would fit in LDS (the kernel that
-    larger scenes and scenes with bounding boxes run); the library reads the variable at every call."""
+    """The grid scan (f32 mode) or the stream kernel (f64 mode) with the grid's tables read from memory even where a
+    copy would fit in LDS (the kernels that larger scenes and scenes with bounding boxes run); the library reads the
+    variable at every call."""
     os.environ["DRAY_GRID_LDS"] = "0"
     try:
         return render_gpu(dray, gpu, spheres, cam, variant=dray.SCAN_GRID, **opts)
@@ -1251,6 +1252,8 @@ def test_f64_stream_kernel_shapes_of_work(dray, gpu, oracle):
             b = render_gpu(dray, gpu, spheres, cam, seed=29, variant=dray.SCAN_HYBRID)   # one thread per pixel
             assert (a[0] == b[0]).all() and (a[1] == b[1]).all() and (a[2] == b[2]).all(), (name, flags)
             assert a[3].segments == b[3].segments and a[3].samples == b[3].samples, (name, flags)
+            m = render_gpu_grid_from_memory(dray, gpu, spheres, cam, seed=29)              # the stream without its LDS copy of the grid
+            assert (a[0] == m[0]).all() and (a[1] == m[1]).all() and a[3].segments == m[3].segments, (name, flags)
         if name in ("1spp", "tiny", "column", "odd"):
             cam.flags = 0
             ocol, oraw, ocnt, ost = oracle.render(ocam_from(oracle, cam), spheres, seed=29, threads=8)
@@ -1323,6 +1326,8 @@ def test_f64_organisations_agree_on_degenerate_cameras_and_scenes(dray, gpu, ora
             b = render_gpu(dray, gpu, spheres, cam, seed=37, variant=dray.SCAN_HYBRID)
             c = render_gpu(dray, gpu, spheres, cam, seed=37, variant=dray.SCAN_SCALAR)
             assert same(a, b) and same(a, c), (name, flags)
+            m = render_gpu_grid_from_memory(dray, gpu, spheres, cam, seed=37)   # the stream kernel without its LDS copy
+            assert same(a, m), (name, flags)
         cam.flags = 0
         ocol, oraw, ocnt, ost = oracle.render(ocam_from(oracle, cam), spheres, seed=37, threads=8)
         a = render_gpu(dray, gpu, spheres, cam, seed=37)

@@ -78,8 +78,8 @@ def main():
             cam.mode, cam.flags = d.MODE_F64, (d.FLAG_ITERATIVE_PRODUCT if k % 2 else 0)
         scene = ddev.DeviceScene(sp, 0)
         res = {}
-        # "memory": the f32 grid scan with its tables read from memory even where they would fit in LDS
-        for variant in (d.SCAN_SCALAR, d.SCAN_HYBRID, d.SCAN_GRID) + (("memory",) if args.mode == "f32" else ()):
+        # "memory": the grid scan (f64: the stream kernel) with the tables read from memory even where a copy fits in LDS
+        for variant in (d.SCAN_SCALAR, d.SCAN_HYBRID, d.SCAN_GRID, "memory"):
             color, raw, count = ddev.alloc_buffers(cam, 0)
             if variant == "memory":
                 os.environ["DRAY_GRID_LDS"] = "0"
