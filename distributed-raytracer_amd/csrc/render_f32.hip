@@ -1177,12 +1177,14 @@ F32Plan plan_render_f32(const CamDev<float>& cam, const Partition& part, int32_t
     const long long sixteenth = (long long)(part.n_rows > 0 ? part.n_rows : 0) * cam.W * spp /
                                 (16LL * plan.grid * (plan.block / 64));
     int32_t ppp = (kPoolSamples + spp - 1) / spp; // >= kPoolSamples samples ...
-    if (plan.scan == DRAY_SCAN_GRID) {
-        // With the grid scan, whose samples are cheap, a pool of some 500 to 1 000 samples is the better unit: a pool is
-        // what a wave asks the queue for at least, and it waits for the answer.  1200x675 frame, ms at 1 / 2 / 4 / 8 pixels
-        // per pool: 500 spp 26.37 / 25.96 / 26.26 / -, 250 spp 13.53 / 13.39 / 13.26 / -, 100 spp 5.83 / 5.74 / 5.72 /
-        // 5.76, 50 spp (2 / 4 / 8 / 12 / 16 pixels) 3.22 / 3.23 / 3.14 / 3.16 / 3.37.  A small launch keeps small pools.
-        int32_t want = (512 + spp - 1) / spp;
+    if (plan.scan == DRAY_SCAN_GRID || scene.n_narrow_padded <= 64) {
+        // Where samples are cheap (the grid scan, a list of a few spheres) a pool of some 800 to 1 000 samples is the
+        // better unit: a pool is what a wave asks the queue for at least, it waits for the answer, and opening one costs
+        // some 200 instructions.  1200x675 frame, grid scan, ms at 1 / 2 / 4 / 8 pixels per pool: 500 spp 26.37 / 25.96 /
+        // 26.26 / -, 250 spp 13.53 / 13.39 / 13.26 / -, 100 spp 5.83 / 5.74 / 5.72 / 5.76, 50 spp (2 / 4 / 8 / 12 / 16
+        // pixels) 3.22 / 3.23 / 3.14 / 3.16 / 3.37; three spheres at 1920x1080x100 spp (1 / 2 / 4 / 8 / 10 / 12 / 16): 8.56 /
+        // 8.41 / 8.80 / 8.07 / 8.08 / 8.14 / 8.25.  A small launch keeps small pools.
+        int32_t want = (800 + spp - 1) / spp;
         if (want > 12) want = 12;
         const int32_t fits = (int32_t)(sixteenth / spp < 12 ? sixteenth / spp : 12);
         if (want > fits) want = fits;
