@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <string>
@@ -782,6 +783,18 @@ struct RenderJob {
         if (stats) *stats = base;
         empty = cam->samples_per_pixel <= 0 || part.n_rows == 0;
         stream = (hipStream_t)stream_v;
+        // what this call cannot serve is refused here, before it has waited on anything or taken a call slot
+        if (noalloc && (size_t)part.n_rows * (size_t)W > kNoAllocMaxPixels) {
+            snprintf(g_detail, sizeof g_detail, "%d rows x %d pixels exceed the %zu pixels of the allocation-free workspace",
+                     part.n_rows, W, kNoAllocMaxPixels);
+            return DRAY_ERR_TOO_LARGE;
+        }
+        if (opts.mode == DRAY_MODE_F32 && opts.variant == DRAY_SCAN_HYBRID &&
+            (size_t)scene->dev.n_narrow_padded * 8u > kHybridLdsLimit) {
+            snprintf(g_detail, sizeof g_detail, "the hybrid scan stages 8 bytes per sphere in LDS: %d spheres exceed its %zu bytes",
+                     scene->dev.n_narrow_padded, kHybridLdsLimit);
+            return DRAY_ERR_UNSUPPORTED;
+        }
         return DRAY_OK;
     }
 
@@ -804,11 +817,6 @@ struct RenderJob {
         // the counters and the f32 kernel's sums: the scene's own (the sums grown when a frame needs more), or the
         // library's static array for the entry point that may not allocate
         if (noalloc) {
-            if ((size_t)part.n_rows * (size_t)W > kNoAllocMaxPixels) {
-                snprintf(g_detail, sizeof g_detail, "%d rows x %d pixels exceed the %zu pixels of the allocation-free workspace",
-                         part.n_rows, W, kNoAllocMaxPixels);
-                return DRAY_ERR_TOO_LARGE;
-            }
             unsigned long long* ws = noalloc_workspace(scene->device);
             if (!ws) return DRAY_ERR_HIP;
             slot->d_counters = (DeviceCounters*)ws;
@@ -824,7 +832,6 @@ struct RenderJob {
         const CamDev<float> c = make_cam<float>(*cam, dv);
         plan = plan_render_f32(c, part, opts.pixels_per_pool, opts.variant, scene->dev, scene->device);
         plan.no_refill = (opts.flags & DRAY_FLAG_NO_REFILL) ? 1 : 0;
-        if (opts.variant == DRAY_SCAN_HYBRID && plan.scan != DRAY_SCAN_HYBRID) return DRAY_ERR_UNSUPPORTED; // table beyond the LDS staging limit
         // The trace kernel runs on the stream of one of the scene's two trace spaces (the allocation-free call: on
         // the caller's stream, over the static workspace); the caller's stream picks up when it has ended.
         hipStream_t trace_stream = stream;
@@ -876,14 +883,19 @@ struct RenderJob {
                           : (opts.variant == DRAY_SCAN_HYBRID || noalloc) ? kRefGridByPixel : kRefGridAsStream;
                 F64StreamPlan sp{};
                 if (how == kRefGridAsStream && !plan_render_f64_stream(c, part, scene->dev, scene->device, &sp)) how = kRefGridByPixel;
-                if (how == kRefGridAsStream) {
-                    if (sp.ring_bytes > scene->rings_bytes) {
-                        if (scene->d_rings) HIP_TRY(hipFree(scene->d_rings)); // waits for the device: no earlier call still uses it
-                        scene->d_rings = nullptr;
-                        scene->rings_bytes = 0;
-                        HIP_TRY(hipMalloc(&scene->d_rings, sp.ring_bytes));
+                if (how == kRefGridAsStream && sp.ring_bytes > scene->rings_bytes) {
+                    if (scene->d_rings) HIP_TRY(hipFree(scene->d_rings)); // waits for the device: no earlier call still uses it
+                    scene->d_rings = nullptr;
+                    scene->rings_bytes = 0;
+                    if (hipMalloc(&scene->d_rings, sp.ring_bytes) == hipSuccess) {
                         scene->rings_bytes = sp.ring_bytes;
+                    } else { // no room for the rings: the kernel that needs no workspace renders the same values
+                        (void)hipGetLastError();
+                        scene->d_rings = nullptr;
+                        how = kRefGridByPixel;
                     }
+                }
+                if (how == kRefGridAsStream) {
                     HIP_TRY(launch_render_f64_stream(c, scene->dev, part, key, opts.flags, sp, d_color, d_raw, d_count,
                                                      d_counters, scene->d_rings, stream));
                 } else {
@@ -1475,29 +1487,30 @@ int context_render_progressive_locked(dray_context* c, const dray_camera* cam, u
 
 // The contexts behind dray_render and dray_render_multi: one per list of devices, kept until dray_release_cache or
 // the end of the process, so that a second call with the same sphere list finds scene, grid and buffers in place.
+// A cached context is shared between the cache and the calls that use it: a call keeps the one it looked up alive for
+// its own length, so a context dropped from the cache (eviction, dray_release_cache) dies when its last user lets go.
 std::mutex g_cache_mu;
-std::vector<std::pair<std::vector<int32_t>, dray_context*>> g_cache;
+std::vector<std::pair<std::vector<int32_t>, std::shared_ptr<dray_context>>> g_cache;
 
 int cached_render(const std::vector<int32_t>& devs, const dray_camera* cam, const dray_sphere* spheres, size_t n,
                   uint32_t* color, double* raw, int32_t* count, size_t buf_len, const dray_opts* opts, dray_stats* stats) {
     const auto t_begin = std::chrono::steady_clock::now();
-    dray_context* c = nullptr;
+    std::shared_ptr<dray_context> held;
     {
         std::lock_guard<std::mutex> lock(g_cache_mu);
         for (auto& e : g_cache)
-            if (e.first == devs) c = e.second;
-        if (!c) {
-            if (g_cache.size() >= 8) { // a handful of device lists at most: drop the oldest
-                std::lock_guard<std::mutex> busy(g_cache.front().second->mu);
-                context_free(g_cache.front().second);
-                g_cache.erase(g_cache.begin());
-            }
-            const int rc = context_create_impl(devs.data(), (int32_t)devs.size(), &c);
+            if (e.first == devs) held = e.second;
+        if (!held) {
+            if (g_cache.size() >= 8) g_cache.erase(g_cache.begin()); // a handful of device lists at most: drop the oldest
+            dray_context* made = nullptr;
+            const int rc = context_create_impl(devs.data(), (int32_t)devs.size(), &made);
             if (rc) return rc;
-            g_cache.emplace_back(devs, c);
+            held = std::shared_ptr<dray_context>(made, context_free);
+            g_cache.emplace_back(devs, held);
         }
     }
-    std::lock_guard<std::mutex> lock(c->mu);
+    dray_context* c = held.get();
+    std::lock_guard<std::mutex> lock(c->mu); // (released before `held`, declared earlier, lets go of the context)
     // argument errors come before any device work, as they always did
     if (!camera_ok(cam) || !color || (!spheres && n)) return DRAY_ERR_INVALID_ARG;
     int rc = context_set_scene_locked(c, spheres, n);
@@ -1758,11 +1771,7 @@ int dray_render_multi(const dray_camera* cam, const dray_sphere* spheres, size_t
 void dray_release_cache(void) {
     try {
         std::lock_guard<std::mutex> lock(g_cache_mu);
-        for (auto& e : g_cache) {
-            { std::lock_guard<std::mutex> busy(e.second->mu); } // a call in flight on another thread finishes first
-            context_free(e.second);
-        }
-        g_cache.clear();
+        g_cache.clear(); // a context still in use by a call on another thread is freed when that call returns
     } catch (...) {
     }
 }

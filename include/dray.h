@@ -198,7 +198,8 @@ int dray_render(const dray_camera* cam, const dray_sphere* spheres, size_t n_sph
 /* The same call over several GPUs of one node from one process, as the single render call of main.rs:86 needs it
  * (the reference spreads a frame over machines through src/distributed; orchestrator_server.rs:59-68 deals the
  * rays out, :253-256 collects the pixels): entry k of `devices` renders scanlines k, k + n_devices, ... with the
- * whole scene replicated, one host thread per entry, and writes its rows straight into the caller's buffers.
+ * whole scene replicated, every share enqueued from the calling thread (no host threads are started), and its rows
+ * go straight into the caller's buffers.
  * Buffers, result and statistics are those of dray_render (kernel_ms: the slowest share).  devices == NULL means
  * devices 0 .. n_devices-1; n_devices <= 0 means every visible GPU; a device may be named more than once.
  * opts->device, row_begin, row_step and DRAY_FLAG_COMPACT_ROWS must be left at their defaults. */
@@ -282,15 +283,17 @@ int dray_render_device_async(const dray_camera* cam, dray_scene* scene, uint32_t
                              size_t buf_len, const dray_opts* opts, void* stream, uint64_t* ticket);
 int dray_scene_collect(dray_scene* scene, uint64_t ticket, dray_stats* stats);
 
-/* dray_render_device for callers that cannot allocate device memory: code under HIP graph capture, tight serving
- * loops, harnesses that forbid hipMalloc.  It has no counterpart in the reference.  Same arguments, same results
+/* dray_render_device for callers that cannot allocate device memory: tight serving loops, harnesses that forbid
+ * hipMalloc.  It has no counterpart in the reference.  Same arguments, same results
  * bit for bit, but the call's workspace (the f32 kernel's fixed-point colour sums, 24 bytes per pixel, and the
  * counters) is a static array in the library's device code instead of buffers the scene allocates and grows: the
  * call never calls hipMalloc or hipFree.  Limits: the rows it renders times image_width may not exceed
  * DRAY_NOALLOC_MAX_PIXELS (DRAY_ERR_TOO_LARGE otherwise); every GPU the library runs on holds its own 25 MiB copy
  * of the array until the process ends; all such calls on one GPU share that GPU's copy, so two of them that
  * overlap in time (different streams or host threads, the same scene or not) race -- keep them on one stream.  With
- * stats the call blocks and copies the counters back (32 bytes); leave stats NULL under graph capture. */
+ * stats the call blocks until the render is done.  Not for a stream that is being captured into a graph: like every
+ * call on a scene it records the scene's events on `stream`, waits on the previous call's, and may synchronise on the
+ * event of the call sixteen calls back. */
 #define DRAY_NOALLOC_MAX_PIXELS 1048576
 int dray_render_device_noalloc(const dray_camera* cam, dray_scene* scene, uint32_t* d_color, double* d_raw,
                                int32_t* d_count, size_t buf_len, const dray_opts* opts, void* stream, dray_stats* stats);

@@ -509,6 +509,23 @@ def test_glass_metal_depth_100(dray, gpu, oracle):
     assert abs(int(st.segments) - int(ost.segments)) <= 0.003 * ost.segments
 
 
+def test_compaction_switch_leaves_the_image_alone(dray, gpu):
+    """DRAY_FLAG_NO_REFILL (wave-level compaction off: idle lanes wait until their whole wave is idle) changes the
+    schedule and nothing else: colours, sums, counts, segment and sample totals equal the default's on the glass / metal
+    scene at depth 100 (paths of 1 to 100 segments) and on the final scene, for every scan the f32 kernel has."""
+    cases = ((dray.scene_glass_metal(3), dray.camera_final(width=120, spp=24, depth=100), 31),
+             (dray.scene_final(1), dray.camera_final(width=128, spp=40, depth=50), 32))
+    for spheres, cam, seed in cases:
+        cam.mode = dray.MODE_F32
+        for variant in (dray.SCAN_AUTO, dray.SCAN_HYBRID, dray.SCAN_SCALAR):
+            on = render_gpu(dray, gpu, spheres, cam, seed=seed, variant=variant)
+            off = render_gpu(dray, gpu, spheres, cam, seed=seed, variant=variant, flags=dray.FLAG_NO_REFILL)
+            assert (on[0] == off[0]).all() and (on[1] == off[1]).all() and (on[2] == off[2]).all(), variant
+            assert on[3].segments == off[3].segments and on[3].samples == off[3].samples, variant
+        off = render_gpu_grid_from_memory(dray, gpu, spheres, cam, seed=seed, flags=dray.FLAG_NO_REFILL)
+        assert (on[1] == off[1]).all() and on[3].segments == off[3].segments
+
+
 def test_full_hd_properties(dray, gpu, oracle):
     """1920 x 1080, 100 samples per pixel, depth 50 on the three-sphere scene (the per-node workload of the
     distributed configuration).  The oracle cannot render the frame in seconds, so: every 90th row against the
