@@ -22,7 +22,39 @@ template <typename T> __device__ __forceinline__ V3<T> vadd(V3<T> a, V3<T> b) { 
 template <typename T> __device__ __forceinline__ V3<T> vsub(V3<T> a, V3<T> b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
 template <typename T> __device__ __forceinline__ V3<T> vmul(V3<T> a, V3<T> b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
 template <typename T> __device__ __forceinline__ V3<T> vscale(V3<T> a, T s) { return {a.x * s, a.y * s, a.z * s}; }
-template <typename T> __device__ __forceinline__ V3<T> vdiv(V3<T> a, T s) { return {a.x / s, a.y / s, a.z / s}; }
+// Three quotients by one divisor (vec3.rs:229-238) -- and, wherever a ray is tested against several spheres, the
+// roots' division by |d|^2 (sphere.rs:38,41).  An IEEE f64 division on gfx950 is a sequence the compiler writes out:
+// both operands scaled if their exponents are extreme (v_div_scale), y = v_rcp_f64 of the divisor refined by two
+// Newton steps, q0 = x y, e = fma(-s, q0, x), q = fma(e, y, q0) (v_div_fmas), special cases patched (v_div_fixup).
+// For operands whose exponents lie in a middle band nothing is scaled and nothing patched, so y depends on the
+// divisor alone: it is formed once and every quotient costs three operations, with the bits the division yields
+// (tools/ubench_div.hip compares the two on the GPU).  Outside the band -- zero, subnormal, huge, infinite, NaN --
+// the division itself is taken.
+__device__ __forceinline__ bool div_band(double x) { // 2^-323 <= |x| < 2^328: no scaling for any pair in the band
+    const uint32_t e = ((uint32_t)__double2hiint(x) >> 20) & 0x7ffu;
+    return e - 700u <= 650u;
+}
+__device__ __forceinline__ double refined_rcp(double s) {
+    const double r0 = __builtin_amdgcn_rcp(s);
+    const double e0 = __builtin_fma(-s, r0, 1.0);
+    const double r1 = __builtin_fma(r0, e0, r0);
+    const double e1 = __builtin_fma(-s, r1, 1.0);
+    return __builtin_fma(r1, e1, r1);
+}
+__device__ __forceinline__ double div_by(double x, double s, double y) { // x / s for y = refined_rcp(s), both in the band
+    const double q0 = x * y;
+    const double e = __builtin_fma(-s, q0, x);
+    return __builtin_fma(e, y, q0);
+}
+template <typename T> __device__ __forceinline__ V3<T> vdiv(V3<T> a, T s) {
+    if constexpr (sizeof(T) == sizeof(double)) {
+        if (div_band(s) && div_band(a.x) && div_band(a.y) && div_band(a.z)) {
+            const double y = refined_rcp(s);
+            return {div_by(a.x, s, y), div_by(a.y, s, y), div_by(a.z, s, y)};
+        }
+    }
+    return {a.x / s, a.y / s, a.z / s};
+}
 template <typename T> __device__ __forceinline__ V3<T> vneg(V3<T> a) { return {-a.x, -a.y, -a.z}; }
 template <typename T> __device__ __forceinline__ T vdot(V3<T> a, V3<T> b) { return a.x * b.x + a.y * b.y + a.z * b.z; } // vec3.rs:64-66
 template <typename T> __device__ __forceinline__ T vlen2(V3<T> a) { return vdot(a, a); }

@@ -27,6 +27,7 @@
 // the scan of the whole list, as there.
 #pragma clang fp contract(off)
 
+#include <cmath>
 #include <cstdlib>
 #include <mutex>
 
@@ -105,25 +106,81 @@ __device__ __forceinline__ Drawn coop_draw64(const Stream& st, const uint32_t (&
     return res;
 }
 
-// A lane's walk through the grid, kept across turns of the main loop.
-struct Walk64 {
-    double A[3], B[3]; // time at which the ray leaves cell k of an axis: k * A + B
-    double slack;
-    int32_t c[3];      // current cell
-    uint32_t e, e_end; // entries of the current cell still to test
-    int32_t steps;
-    double closest;    // smallest accepted root so far, and its sphere's list position
-    int32_t best;
+// ---- closest hit: a conservative f32 search in front of the reference's f64 test --------------------------------
+// The reference's scan returns the minimum over (root, list position) of the roots sphere.rs:29-48 accepts.  Which
+// spheres can hold that minimum is found in f32 -- a walk through the grid with a test that brackets every sphere's
+// root between bounds no rounding can cross -- and only those (one or two per ray) take the reference's own f64
+// expressions (sphere_root_of), so root, point and normal are bit for bit the linear scan's.
+//
+// The f32 view of a ray: origin moved along the ray up to the ball that holds the narrow spheres (so that its
+// coordinates are of the scene's size), unit direction, and the reference's lower bound 0.001 |d| in arc length from
+// that origin.  For a sphere (centre c~, squared radius r2~, both rounded to f32) the test forms oc = c~ - o~, h = oc.u~,
+// disc = h^2 + r2~ - |oc|^2 and brackets the true values (those of the unrounded ray and sphere in real arithmetic, which
+// the reference's f64 results match to ~2^-50 of the same magnitudes):
+//   |disc - disc*| <= E  = 2^-18 (|oc|^2 + r2) + 2^-19 |o~| |oc| + 2^-26 |o~|^2      (measured bound: 26, 14 and 0 units of 2^-24)
+//   |h - h*|       <= Eh = 2^-20 (|oc| + |o~| + sqrt(disc + E))                       (measured bound: 8 and 4 units of 2^-24)
+// with |o~| enlarged by 2^-9 of the distance the origin was moved, which covers the f64 rounding of the reference's own
+// expressions seen from the unmoved origin (2^-50 of that distance squared in disc, 2^-50 of it in h).  Hence
+//   near root in [h - sqrt(disc + E) - Eh, h - sqrt(disc - E) + Eh],  far root in [h + sqrt(disc - E) - Eh, h + sqrt(disc + E) + Eh],
+// a sphere with disc + E < 0 or far bound below the lower bound is missed for certain, one with disc - E > 0 and a root
+// bound above the lower bound is hit for certain and caps the search (`ub`); everything in between stays a candidate.
+// Values that are not finite fail every comparison and so stay candidates too.
+struct Filter32 {
+    float ox, oy, oz, ux, uy, uz;
+    float tm_lo, tm_hi; // the reference's lower bound on a root (interval.rs:28-30), a hair below and above
+    float on;           // |o~| + 2^-9 of the move
+};
+constexpr uint32_t kNoCand = 0xFFFFFFFFu;
+struct Cand {
+    float ub;        // an upper bound on the closest accepted root, from spheres hit for certain (and the wide spheres' exact roots)
+    uint32_t i0, i1; // list positions of the spheres that may hold the closest root (kNoCand: free slot)
 };
 
-// One sphere (centre, radius, position in the caller's list) against the walk's closest hit so far.
-__device__ __forceinline__ void test64(V3<double> center, double radius, int32_t k, V3<double> ro, V3<double> rd, Walk64& w) {
-    double root;
-    if (sphere_root_of<double>(center, radius, ro, rd, root) && (root < w.closest || (root == w.closest && k < w.best))) {
-        w.closest = root;
-        w.best = k;
-    }
+// One sphere against the search so far.  Returns true when the sphere is a candidate and both slots are taken: the
+// caller has the slots evaluated and tests the sphere again.
+__device__ __forceinline__ bool filter_test(const Filter32& f, float cx, float cy, float cz, float r2, uint32_t k, Cand& c) {
+    const float ocx = cx - f.ox, ocy = cy - f.oy, ocz = cz - f.oz;
+    const float h = fmaf(ocz, f.uz, fmaf(ocy, f.uy, ocx * f.ux));
+    const float oc2 = fmaf(ocz, ocz, fmaf(ocy, ocy, ocx * ocx));
+    const float disc = fmaf(h, h, r2 - oc2);
+    const float ocn = __builtin_amdgcn_sqrtf(oc2);
+    // (the floors 1e-30 and 1e-15 stand above anything f32 underflow can do to a scene of the sizes the search is used for)
+    const float e = fmaf(1.9073486328125e-06f * f.on, ocn, fmaf(1.4901161193847656e-08f * f.on, f.on, fmaf(3.814697265625e-06f, oc2 + r2, 1e-30f)));
+    const float dhi = disc + e, dlo = disc - e;
+    const float sq_hi = __builtin_amdgcn_sqrtf(fmaxf(dhi, 0.f)), sq_lo = __builtin_amdgcn_sqrtf(fmaxf(dlo, 0.f));
+    const float eh = fmaf(9.5367431640625e-07f, ocn + f.on + sq_hi, 1e-15f);
+    const float near_lo = (h - sq_hi) - eh, near_hi = (h - sq_lo) + eh;
+    const float far_lo = (h + sq_lo) - eh, far_hi = (h + sq_hi) + eh;
+    const bool miss = (dhi < 0.f) | (far_hi < f.tm_lo);
+    const float lo = near_hi < f.tm_lo ? far_lo : near_lo;
+    const bool sure_near = near_lo > f.tm_hi;
+    const bool certain = (dlo > 0.f) & (sure_near | (far_lo > f.tm_hi));
+    const float hi = sure_near ? near_hi : far_hi;
+    // a sphere met again (it is listed in several cells) is not taken twice
+    const bool keep = !miss & !(lo > c.ub) & (k != c.i0) & (k != c.i1);
+    c.ub = (certain & keep & (hi < c.ub)) ? hi : c.ub;
+    const bool free0 = c.i0 == kNoCand, free1 = c.i1 == kNoCand;
+    c.i1 = (keep & !free0 & free1) ? k : c.i1;
+    c.i0 = (keep & free0) ? k : c.i0;
+    return keep & !free0 & !free1;
 }
+
+// A lane's walk through the grid (3-D DDA along the f32 ray), kept across turns of the main loop.  Boundary times are
+// recomputed from the cell index at every step, never accumulated; the walk stops when `ub` lies before the current
+// cell's exit by more than the exit time's rounding error.  A sphere is listed in every cell its ball grown by 1/256
+// cell (and 1e-5 of the scene's reach) overlaps, which the f32 rounding of ray and walk cannot bridge.
+struct Walk32 {
+    float c[3];        // current cell (small integers, exact in f32)
+    uint32_t e, e_end; // entries of the current cell still to test
+};
+// What stays the same for the length of a ray -- the f32 view of the ray and the walk's boundary times (the ray leaves
+// cell k of an axis at fma(k, A, B); `slack` bounds the rounding error of those times) -- is kept in LDS, sixteen words
+// per lane, and read at the head of every turn's steps: registers are what this kernel is short of (the shading
+// sections between two turns' steps need none of it).
+struct RayConst {
+    float A[3], B[3], slack;
+    Filter32 f;
+};
 
 // Diagnostic builds only (tools/f64_clocks.py): with DRAY_F64_CLOCKS a wave adds up the shader clocks it spends in
 // each section of its main loop, and how often a few things happen.
@@ -142,8 +199,10 @@ __device__ unsigned long long dray_f64_clocks[32];
 #endif
 
 // One finished sample in a wave's ring: the colour that joins the pixel's sum (camera.rs:223-225: 0 + sample).
-struct RingEntry {
-    double r, g, b;
+typedef double D2 __attribute__((ext_vector_type(2)));
+struct __attribute__((aligned(32))) RingEntry {
+    D2 rg;   // one 16-byte store
+    double b;
     double unused; // entries are 32 bytes apart
 };
 static_assert(sizeof(RingEntry) == 32, "ring entries are 32 bytes apart");
@@ -152,6 +211,8 @@ constexpr uint32_t kFifoSlots = 16; // chunks a wave may have grabbed and not be
 #ifndef DRAY_F64_WAVES_PER_EU
 #define DRAY_F64_WAVES_PER_EU 4
 #endif
+
+typedef float V4f __attribute__((ext_vector_type(4))); // a float4 that can be read through any address space
 
 // Everything a launch of the stream kernel is given.  The kernel reads it where it is used, straight from the
 // kernel-argument segment (scalar loads), instead of holding all of it in scalar registers for the whole launch.
@@ -171,13 +232,22 @@ struct F64Args {
     RingEntry* rings;
     uint32_t chunk_pixels;
     int32_t n_cells, n_entries; // the grid's tables (the kernel that stages a copy of the grid in LDS)
+    // the f32 search (Filter32): the narrow spheres' rows cx, cy, cz, r*r and their list positions, the ball that holds
+    // them (centre, radius; radius +inf: no narrow sphere), and the limits inside which the search may be trusted
+    const V4f* narrow_geom;
+    const int32_t* narrow_index;
+    int32_t n_narrow_padded;
+    int32_t filter_ok;   // the scene's size is one f32 arithmetic has room for
+    double ball[4];
+    double ball_far2;    // an origin farther than this (squared) from the ball's centre after the move: the ray passes the ball by
+    double reach;        // largest origin coordinate the move is made for (beyond: the scan of the whole list)
 };
 
 // The copy of the grid a workgroup of the LDS kernel stages at its entry, so compact that four workgroups' copies fit
-// a compute unit: the spheres' rows (cx, cy, cz, radius: the f64 geometry table as it is, by list position), then a
-// word per cell -- first entry (12 bits) | entry count (4 bits) | list position of the first entry's sphere (16 bits)
-// --, then the entries as 16-bit list positions.  A lane entering a cell has its first sphere from the cell's word, a
-// lane staying in its cell reads the entry table: two dependent reads per step, both from LDS.
+// a compute unit: the narrow spheres' f32 rows (cx, cy, cz, r*r) by list position, then a word per cell -- first entry
+// (12 bits) | entry count (4 bits) | list position of the first entry's sphere (16 bits) --, then the entries as 16-bit
+// list positions.  A lane entering a cell has its first sphere from the cell's word, a lane staying in its cell reads
+// the entry table: two dependent reads per step, both from LDS.
 constexpr uint32_t kLds64BeginBits = 12u, kLds64CountBits = 4u;
 
 // Hides where a pointer came from, so that reads through it are not moved across this point.
@@ -188,19 +258,51 @@ __device__ __forceinline__ const DRAY_CONSTANT T* opaque(const DRAY_CONSTANT T* 
     return (const DRAY_CONSTANT T*)v;
 }
 
+// sphere.rs:28-48 for one sphere against the closest hit so far (smallest root, on equal roots the earlier entry),
+// with the two possible divisions by |d|^2 made from one refined reciprocal where the operands allow (div_by).
+__device__ __forceinline__ void exact_test(V3<double> center, double radius, int32_t k, V3<double> ro, V3<double> rd,
+                                           double& closest, int32_t& best) {
+    const double tmin = 0.001;
+    V3<double> oc = vsub(center, ro);
+    double a = vlen2(rd);
+    double h = vdot(rd, oc);
+    double c = vlen2(oc) - radius * radius;
+    double discriminant = h * h - a * c;
+    if (discriminant < 0.) return;
+    double sqrtd = vsqrt(discriminant);
+    const bool a_ok = div_band(a);
+    const double y = refined_rcp(a);
+    double num = h - sqrtd;
+    double root = (a_ok && div_band(num)) ? div_by(num, a, y) : num / a;
+    if (!(tmin < root)) { // interval.rs:28-30, strict
+        num = h + sqrtd;
+        root = (a_ok && div_band(num)) ? div_by(num, a, y) : num / a;
+        if (!(tmin < root)) return;
+    }
+    if (root < INFINITY && (root < closest || (root == closest && k < best))) {
+        closest = root;
+        best = k;
+    }
+}
+
 template <bool ITERATIVE, bool LDSGRID>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DRAY_F64_WAVES_PER_EU, DRAY_F64_WAVES_PER_EU)))
 void render_f64_stream_kernel(F64Args) {
     const DRAY_CONSTANT F64Args* ka = (const DRAY_CONSTANT F64Args*)__builtin_amdgcn_kernarg_segment_ptr();
-    extern __shared__ double lds_geom[]; // LDSGRID: rows of four doubles by list position, then the cell words, then the entries
+    extern __shared__ V4f lds_rows[]; // LDSGRID: f32 rows by list position, then the cell words, then the entries
     if constexpr (LDSGRID) {
-        const int32_t n4 = 4 * ka->n, n_cells = ka->n_cells, n_entries = ka->n_entries;
-        const double* geom = ka->geom;
+        const int32_t n_list = ka->n, n_cells = ka->n_cells, n_entries = ka->n_entries;
+        const DRAY_CONSTANT V4f* narrow_geom = as_constant(ka->narrow_geom);
+        const DRAY_CONSTANT int32_t* narrow_index = as_constant(ka->narrow_index);
         const uint2* cells = ka->rg.grid.cells;
         const int32_t* entry_index = ka->rg.entry_index;
-        uint32_t* lds_cells = (uint32_t*)(lds_geom + n4);
+        uint32_t* lds_cells = (uint32_t*)(lds_rows + n_list);
         uint16_t* lds_entries = (uint16_t*)(lds_cells + n_cells);
-        for (int32_t k = threadIdx.x; k < n4; k += blockDim.x) lds_geom[k] = geom[k];
+        // (rows of list positions that hold no narrow sphere -- wide spheres -- are never read: no entry names them)
+        for (int32_t k = threadIdx.x; k < ka->n_narrow_padded; k += blockDim.x) {
+            const int32_t at = narrow_index[k];
+            if (at >= 0 && at < n_list) lds_rows[at] = narrow_geom[k];
+        }
         for (int32_t k = threadIdx.x; k < n_cells; k += blockDim.x) {
             const uint2 rec = cells[k];
             const uint32_t first = rec.y != 0u ? (uint32_t)entry_index[rec.x] : 0u;
@@ -210,9 +312,9 @@ void render_f64_stream_kernel(F64Args) {
         __syncthreads(); // the only block-wide wait: once, before any work is drawn
     }
     // the cell's record: first entry, entry count, and (LDSGRID) the first entry's sphere
-    auto cell_of = [&](size_t ci, uint32_t& first_sphere) -> uint2 {
+    auto cell_of = [&](uint32_t ci, uint32_t& first_sphere) -> uint2 {
         if constexpr (LDSGRID) {
-            const uint32_t rec = ((const uint32_t*)(lds_geom + 4 * ka->n))[ci];
+            const uint32_t rec = ((const uint32_t*)(lds_rows + ka->n))[ci];
             first_sphere = rec >> (kLds64BeginBits + kLds64CountBits);
             return make_uint2(rec & ((1u << kLds64BeginBits) - 1u), (rec >> kLds64BeginBits) & ((1u << kLds64CountBits) - 1u));
         } else {
@@ -220,14 +322,19 @@ void render_f64_stream_kernel(F64Args) {
             return ka->rg.grid.cells[ci];
         }
     };
-    __shared__ uint4 lds_req[4][64];           // coop_draw64: streams handed to server lanes, one set of slots per wave
+    // per wave: the colours of the samples being retired, 64 x 3 doubles -- and, in another section of the turn, the
+    // streams coop_draw64 hands to server lanes, 64 x 16 bytes, in the same place (LDS keeps one wave's accesses in order)
+    __shared__ double lds_stage_all[4][64][3];
     __shared__ uint32_t lds_fifo[4][kFifoSlots]; // first pixel of the chunks the wave has grabbed, oldest first
-    __shared__ double lds_stage[4][64][3];       // the colours of the samples being retired
+    __shared__ V4f lds_ray[4][4][64];            // RayConst of every lane: [wave][A slack | B on | o tm_lo | u tm_hi][lane]
+    __shared__ double lds_acc[4][4];             // running sum of the pixel the wave is retiring: red, green, blue
+    static_assert(sizeof(lds_stage_all[0]) >= 64 * sizeof(uint4), "the draw requests share the retirement's staging");
     const int lane = (int)(threadIdx.x & 63u), wv = (int)(threadIdx.x >> 6);
+    double (*lds_stage)[3] = lds_stage_all[wv];
+    uint4* lds_req = (uint4*)&lds_stage_all[wv][0][0];
     const uint32_t W = (uint32_t)ka->cam.W, spp = (uint32_t)ka->cam.spp, npix = (uint32_t)ka->part.n_rows * W;
     constexpr bool iterative = ITERATIVE; // how a sample's attenuations are multiplied (camera.rs:130 or :274)
     RingEntry* ring = ka->rings + (size_t)(blockIdx.x * 4u + (uint32_t)wv) * kF64RingEntries;
-    const int32_t max_steps = ka->rg.grid.n[0] + ka->rg.grid.n[1] + ka->rg.grid.n[2] + 4;
     unsigned long long my_segments = 0;
 
     // where partition pixel `pp` lives: its place in the caller's buffers and its Philox pixel word j * W + i
@@ -247,11 +354,13 @@ void render_f64_stream_kernel(F64Args) {
     bool has = false;      // the lane carries a sample
     bool camera = false;   // ... whose camera ray is still to be made
     bool walking = false;  // on its way through the grid
+    bool paused = false;   // ... and stopped with both candidate slots taken: they are evaluated, then the walk goes on
     bool dead = false;     // the path was absorbed: the sample ends black at the lane's next turn
     bool fallback = false; // the closest hit of this ray comes from the scan of the whole list
-    Walk64 wk = {};
-    wk.closest = INFINITY;
-    wk.best = 0x7fffffff;
+    Walk32 wk = {};
+    Cand cd = {INFINITY, kNoCand, kNoCand};
+    double closest = INFINITY; // smallest root the reference's test has accepted so far, and its sphere's list position
+    int32_t best = 0x7fffffff;
 
     // wave state (the same in every lane)
     uint32_t issued = 0u, retired = 0u;       // samples of the wave's stream handed out / added to their pixels
@@ -259,7 +368,6 @@ void render_f64_stream_kernel(F64Args) {
     uint32_t iss_p0 = 0u, iss_q = 0u, iss_n = 0u;     // the chunk being handed out: first pixel, next sample, samples
     uint32_t ret_p0 = 0u, ret_dp = 0u, ret_np = 0u, ret_s = 0u; // the chunk being retired: first pixel, pixel, pixels; sample
     size_t ret_out = 0;
-    double acc = 0.;                          // running sum of the pixel being retired: lane 0 red, 1 green, 2 blue
     unsigned long long n_samples = 0ull;
     bool exhausted = false;
 
@@ -274,6 +382,10 @@ void render_f64_stream_kernel(F64Args) {
         // ---- walk steps, while enough lanes are on their way --------------------------------------------------
         {
             const int quorum = exhausted ? 1 : DRAY_F64_WALK_QUORUM;
+            const float gn0 = (float)ka->rg.grid.n[0], gn1 = (float)ka->rg.grid.n[1], gn2 = (float)ka->rg.grid.n[2];
+            const V4f q0 = lds_ray[wv][0][lane], q1 = lds_ray[wv][1][lane], q2 = lds_ray[wv][2][lane], q3 = lds_ray[wv][3][lane];
+            const float wA[3] = {q0.x, q0.y, q0.z}, wB[3] = {q1.x, q1.y, q1.z}, wslack = q0.w;
+            const Filter32 flt = {q2.x, q2.y, q2.z, q3.x, q3.y, q3.z, q2.w, q3.w, q1.w};
             do { // at least one step a turn: fewer lanes than a quorum may be all the wave has
                 F64_COUNT(18, 1);                              // walk steps
                 F64_COUNT(19, __popcll(__ballot(walking)));    // lanes walking at them
@@ -281,42 +393,41 @@ void render_f64_stream_kernel(F64Args) {
                     uint32_t sphere = 0u; // LDSGRID: list position of the sphere this step tests
                     bool entered = false;
                     if (wk.e == wk.e_end) { // this cell is done: stop, or step into the next one
-                        const double tx = (double)wk.c[0] * wk.A[0] + wk.B[0], ty = (double)wk.c[1] * wk.A[1] + wk.B[1],
-                                     tz = (double)wk.c[2] * wk.A[2] + wk.B[2];
-                        const double t_exit = fmin(tx, fmin(ty, tz));
-                        const bool stop = wk.closest < t_exit * (1. - 1e-9) - wk.slack; // nothing beyond this cell can be closer
-                        const int ax = (tx <= ty && tx <= tz) ? 0 : (ty <= tz ? 1 : 2);
-                        const double Aax = ax == 0 ? wk.A[0] : (ax == 1 ? wk.A[1] : wk.A[2]);
-                        const int32_t dir = Aax < 0. ? -1 : 1;
-                        wk.c[0] += ax == 0 ? dir : 0;
-                        wk.c[1] += ax == 1 ? dir : 0;
-                        wk.c[2] += ax == 2 ? dir : 0;
-                        const int32_t moved = ax == 0 ? wk.c[0] : (ax == 1 ? wk.c[1] : wk.c[2]);
-                        const int32_t limit = ax == 0 ? ka->rg.grid.n[0] : (ax == 1 ? ka->rg.grid.n[1] : ka->rg.grid.n[2]);
-                        const bool inside = moved >= 0 && moved < limit;
-                        bool go = inside && !stop;
-                        if (go && ++wk.steps > max_steps) { // cannot happen on a straight line: take the whole list
-                            fallback = true;
-                            go = false;
-                        }
+                        const float tx = fmaf(wk.c[0], wA[0], wB[0]), ty = fmaf(wk.c[1], wA[1], wB[1]), tz = fmaf(wk.c[2], wA[2], wB[2]);
+                        const float t_exit = fminf(tx, fminf(ty, tz));
+                        const bool stop = cd.ub < fmaf(t_exit, 1.f - 3.814697265625e-6f, -wslack); // nothing beyond this cell can be closer
+                        const bool sx = (tx <= ty) & (tx <= tz);
+                        const bool sy = !sx & (ty <= tz);
+                        // one step along the axis left first; A carries the direction's sign (a parallel axis is never chosen)
+                        wk.c[0] += sx ? copysignf(1.f, wA[0]) : 0.f;
+                        wk.c[1] += sy ? copysignf(1.f, wA[1]) : 0.f;
+                        wk.c[2] += (sx | sy) ? 0.f : copysignf(1.f, wA[2]);
+                        const float moved = sx ? wk.c[0] : (sy ? wk.c[1] : wk.c[2]), limit = sx ? gn0 : (sy ? gn1 : gn2);
+                        const bool inside = (moved >= 0.f) & (moved < limit);
+                        const bool go = inside & !stop;
                         walking = go;
-                        const uint2 cellrec = cell_of(go ? ((size_t)wk.c[2] * ka->rg.grid.n[1] + wk.c[1]) * ka->rg.grid.n[0] + wk.c[0] : 0, sphere);
+                        const uint32_t ci = (uint32_t)fmaf(fmaf(wk.c[2], gn1, wk.c[1]), gn0, wk.c[0]);
+                        const uint2 cellrec = cell_of(go ? ci : 0u, sphere);
                         wk.e = cellrec.x;
                         wk.e_end = go ? cellrec.x + cellrec.y : cellrec.x;
                         entered = true;
                     }
-                    if constexpr (LDSGRID) {
-                        if (!entered && wk.e != wk.e_end) // (beside the other lanes' cell read: the two do not depend on one another)
-                            sphere = ((const uint16_t*)((const uint32_t*)(lds_geom + 4 * ka->n) + ka->n_cells))[wk.e];
-                        if (wk.e != wk.e_end) {
-                            const double* eg = lds_geom + 4 * (size_t)sphere;
-                            test64(V3<double>{eg[0], eg[1], eg[2]}, eg[3], (int32_t)sphere, ro, rd, wk);
+                    if (wk.e != wk.e_end) {
+                        V4f row;
+                        if constexpr (LDSGRID) {
+                            if (!entered) // (beside the other lanes' cell read: the two do not depend on one another)
+                                sphere = ((const uint16_t*)((const uint32_t*)(lds_rows + ka->n) + ka->n_cells))[wk.e];
+                            row = lds_rows[sphere];
+                        } else {
+                            row = ((const V4f*)ka->rg.grid.entry_geom)[wk.e];
+                            sphere = (uint32_t)ka->rg.grid.entry_index[wk.e];
+                        }
+                        if (filter_test(flt, row.x, row.y, row.z, row.w, sphere, cd)) { // both slots taken: evaluate them, then go on
+                            paused = true;
+                            walking = false;
+                        } else {
                             ++wk.e;
                         }
-                    } else if (wk.e != wk.e_end) {
-                        const double* eg = ka->rg.entry_geom64 + 4 * (size_t)wk.e;
-                        test64(V3<double>{eg[0], eg[1], eg[2]}, eg[3], ka->rg.entry_index[wk.e], ro, rd, wk);
-                        ++wk.e;
                     }
                 }
             } while (__popcll(__ballot(walking)) >= quorum);
@@ -343,10 +454,12 @@ void render_f64_stream_kernel(F64Args) {
             const RingEntry* e = ring + ((retired + (uint32_t)lane) & (kF64RingEntries - 1u));
             // (lanes past n_ok read entries nobody uses.)  The colours go through LDS to lanes 0, 1, 2, which add up
             // one channel each, sample after sample: one load and one addition per sample
-            lds_stage[wv][lane][0] = e->r;
-            lds_stage[wv][lane][1] = e->g;
-            lds_stage[wv][lane][2] = e->b;
+            const D2 rg = e->rg;
+            lds_stage[lane][0] = rg.x;
+            lds_stage[lane][1] = rg.y;
+            lds_stage[lane][2] = e->b;
             const int ch = lane < 3 ? lane : 2;
+            double acc = lds_acc[wv][ch]; // lane 0 red, 1 green, 2 blue
             int k = 0;
             while (k < n_ok) {
                 if (ret_s == 0u) { // a pixel begins
@@ -362,7 +475,7 @@ void render_f64_stream_kernel(F64Args) {
                 }
                 const int take = min(n_ok - k, (int)(spp - ret_s));
 #pragma unroll 8
-                for (int t = 0; t < take; ++t) acc += lds_stage[wv][k + t][ch]; // colors.rs:38
+                for (int t = 0; t < take; ++t) acc += lds_stage[k + t][ch]; // colors.rs:38
                 k += take;
                 ret_s += (uint32_t)take;
                 if (ret_s == spp) { // the pixel is complete
@@ -378,11 +491,30 @@ void render_f64_stream_kernel(F64Args) {
                     ret_dp++;
                 }
             }
+            if (lane < 3) lds_acc[wv][lane] = acc;
             retired += (uint32_t)n_ok;
             n_samples += (unsigned long long)n_ok;
         }
 
         F64_CLOCK(3);
+        // ---- lanes whose search is over, or has stopped with its slots full: the candidates take the reference's test ----
+        {
+            const bool settle = has && !walking && !camera && !dead && !fallback && depth > 0;
+            if (__ballot(settle && (cd.i0 != kNoCand || cd.i1 != kNoCand)) != 0ull) {
+                const uint32_t k0 = settle ? cd.i0 : kNoCand, k1 = settle ? cd.i1 : kNoCand;
+                // both rows are asked for before either is used: one trip to memory
+                const double* g0 = ka->geom + 4 * (size_t)(k0 != kNoCand ? k0 : 0u);
+                const double* g1 = ka->geom + 4 * (size_t)(k1 != kNoCand ? k1 : 0u);
+                const D2 g0a = *(const D2*)g0, g0b = *(const D2*)(g0 + 2), g1a = *(const D2*)g1, g1b = *(const D2*)(g1 + 2);
+                if (k0 != kNoCand) exact_test(V3<double>{g0a.x, g0a.y, g0b.x}, g0b.y, (int32_t)k0, ro, rd, closest, best);
+                if (k1 != kNoCand) exact_test(V3<double>{g1a.x, g1a.y, g1b.x}, g1b.y, (int32_t)k1, ro, rd, closest, best);
+                if (settle) cd.i0 = cd.i1 = kNoCand;
+            }
+            if (paused) { // the sphere the walk stopped at is tested again at the next step, with the slots free
+                walking = true;
+                paused = false;
+            }
+        }
         // ---- lanes whose walk is over: the hit (hittable_list.rs:60-74 / sphere.rs:49-55), or the sky -----------
         // (which sphere or box and how far is all that is settled here; point and normal are made where the scatter
         // needs them, after the wave's draws, so that they do not sit in registers through those)
@@ -395,19 +527,19 @@ void render_f64_stream_kernel(F64Args) {
                 ended = true;
             } else {
                 if (fallback) { // the reference's own scan, hittable_list.rs:65-70
-                    wk.closest = INFINITY;
-                    wk.best = 0x7fffffff;
+                    closest = INFINITY;
+                    best = 0x7fffffff;
                     for (int32_t k = 0; k < ka->n; ++k) {
                         double root;
-                        if (sphere_root<double>(ka->geom, k, ro, rd, root) && root < wk.closest) {
-                            wk.closest = root;
-                            wk.best = k;
+                        if (sphere_root<double>(ka->geom, k, ro, rd, root) && root < closest) {
+                            closest = root;
+                            best = k;
                         }
                     }
                 }
-                is_box = boxes_closest<double>(BoxList{ka->rg.box64, ka->rg.box_index, ka->rg.n_boxes}, ro, rd, wk.closest, wk.best);
-                if (wk.best != 0x7fffffff) {
-                    mk = ka->kind[wk.best];
+                is_box = boxes_closest<double>(BoxList{ka->rg.box64, ka->rg.box_index, ka->rg.n_boxes}, ro, rd, closest, best);
+                if (best != 0x7fffffff) {
+                    mk = ka->kind[best];
                     scatters = true;
                 } else {
                     V3<double> ud = vunit(rd); // camera.rs:279-281
@@ -440,8 +572,7 @@ void render_f64_stream_kernel(F64Args) {
                 }
             }
             RingEntry* e = ring + (item & (kF64RingEntries - 1u));
-            e->r = 0. + c.x; // camera.rs:223-225: pixel_color = (0, 0, 0) + sample
-            e->g = 0. + c.y;
+            e->rg = D2{0. + c.x, 0. + c.y}; // camera.rs:223-225: pixel_color = (0, 0, 0) + sample
             e->b = 0. + c.z;
             dead = false;
             has = false;
@@ -504,15 +635,15 @@ void render_f64_stream_kernel(F64Args) {
                               : (camera && ka->cam.defocus != 0)                                      ? (uint32_t)kDraw64UnitDisk
                                                                                                   : (uint32_t)kDraw64None;
         F64_CLOCK(5);
-        const Drawn got = coop_draw64(st, w, draw, lds_req[wv], lane);
+        const Drawn got = coop_draw64(st, w, draw, lds_req, lane);
         F64_CLOCK(6);
 
         // ---- scatter: material.rs -------------------------------------------------------------------------
         bool fresh = false;
         if (scatters) {
             Hit<double> rec; // sphere.rs:49-55
-            if (is_box) box_record<double>(ro, rd, wk.closest, wk.best, rec);
-            else fill_hit<double>(ka->geom, wk.best, ro, rd, wk.closest, rec);
+            if (is_box) box_record<double>(ro, rd, closest, best, rec);
+            else fill_hit<double>(ka->geom, best, ro, rd, closest, rec);
             V3<double> so = ro, sd;
             const bool scattered = scatter_with<double>(
                 mk, ka->mat + 4 * rec.index, rd, rec,
@@ -557,69 +688,101 @@ void render_f64_stream_kernel(F64Args) {
         }
 
         F64_CLOCK(8);
-        // ---- a new ray: the spheres every ray meets, then its first cell ------------------------------------------
+        // ---- a new ray: the wide spheres in f64, the f32 view of the ray, the loose spheres, the first cell ------
         if (fresh) {
             my_segments++;
-            wk.closest = INFINITY;
-            wk.best = 0x7fffffff;
+            closest = INFINITY;
+            best = 0x7fffffff;
+            cd = {INFINITY, kNoCand, kNoCand};
             wk.e = wk.e_end = 0u;
-            wk.steps = 0;
-            fallback = false;
             walking = false;
-            const double o[3] = {ro.x, ro.y, ro.z}, d[3] = {rd.x, rd.y, rd.z};
-            bool finite = true;
-#pragma unroll
-            for (int a = 0; a < 3; ++a) finite = finite && fabs(o[a]) < 1e300 && fabs(d[a]) < 1e300; // false for NaN too
-            if (!finite) {
-                fallback = true;
-            } else {
-                {
+            paused = false;
+            const double a = vlen2(rd);
+            const double omax = fmax(fabs(ro.x), fmax(fabs(ro.y), fabs(ro.z)));
+            // Not for the f32 search: rays that are not finite (NaN fails every comparison), directions whose squared
+            // length leaves the middle of the f64 range, origins so far from the scene that the move to the ball would
+            // lose the ray in f64 rounding, scenes of a size f32 has no room for.  Those take the scan of the whole list.
+            fallback = !(omax <= ka->reach && fabs(rd.x) < 1e300 && fabs(rd.y) < 1e300 && fabs(rd.z) < 1e300 && a >= 1e-200 &&
+                         a <= 1e200 && ka->filter_ok != 0);
+            if (!fallback) {
+                { // the wide spheres take the reference's test at once (scalar loads): in f32 their |oc|^2 - r^2 cancels
                     const DRAY_CONSTANT double* ag = as_constant(ka->rg.always_geom64);
                     const DRAY_CONSTANT int32_t* ai = as_constant(ka->rg.always_index);
-                    // the wide and the loose spheres (scalar loads), four at a time so that their chains of f64
-                    // operations run side by side
-                    const int32_t n_always = ka->rg.n_always;
-                    int32_t q = 0;
-                    for (; q + 4 <= n_always; q += 4) {
-#pragma unroll
-                        for (int u = 0; u < 4; ++u)
-                            test64(V3<double>{ag[4 * (q + u)], ag[4 * (q + u) + 1], ag[4 * (q + u) + 2]}, ag[4 * (q + u) + 3],
-                                   ai[q + u], ro, rd, wk);
-                    }
-                    for (; q < n_always; ++q)
-                        test64(V3<double>{ag[4 * q], ag[4 * q + 1], ag[4 * q + 2]}, ag[4 * q + 3], ai[q], ro, rd, wk);
+                    const int32_t n_wide = ka->rg.n_wide;
+                    for (int32_t q = 0; q < n_wide; ++q)
+                        exact_test(V3<double>{ag[4 * q], ag[4 * q + 1], ag[4 * q + 2]}, ag[4 * q + 3], ai[q], ro, rd, closest, best);
                 }
-                if (ka->rg.grid.n[0] > 0) {
-                    double t_in = 0., t_out = INFINITY, bmax = 0.;
-                    bool inside_slabs = true;
+                // unit direction (v_rsq_f64 is good to 2^-23; one Newton step makes it 2^-40), and the origin moved along
+                // the ray up to the ball of the narrow spheres
+                double il = __builtin_amdgcn_rsq(a);
+                il = il * __builtin_fma(-0.5 * a, il * il, 1.5);
+                const double len = a * il;
+                const V3<double> u = {rd.x * il, rd.y * il, rd.z * il};
+                const V3<double> cb = {ka->ball[0], ka->ball[1], ka->ball[2]};
+                const double hb = __builtin_fma(cb.z - ro.z, u.z, __builtin_fma(cb.y - ro.y, u.y, (cb.x - ro.x) * u.x));
+                const double s0 = fmax(hb - ka->ball[3], 0.);
+                const V3<double> om = {__builtin_fma(s0, u.x, ro.x), __builtin_fma(s0, u.y, ro.y), __builtin_fma(s0, u.z, ro.z)};
+                const V3<double> mb = vsub(cb, om);
+                const bool passes_by = __builtin_fma(mb.z, mb.z, __builtin_fma(mb.y, mb.y, mb.x * mb.x)) > ka->ball_far2;
+                RayConst rc;
+                Filter32& flt = rc.f;
+                flt.ox = (float)om.x; flt.oy = (float)om.y; flt.oz = (float)om.z;
+                flt.ux = (float)u.x; flt.uy = (float)u.y; flt.uz = (float)u.z;
+                const float tm = (float)__builtin_fma(0.001, len, -s0);
+                flt.tm_lo = fmaf(-4.76837158203125e-07f, fabsf(tm), tm);
+                flt.tm_hi = fmaf(4.76837158203125e-07f, fabsf(tm), tm);
+                flt.on = fmaf(0.001953125f, (float)s0, __builtin_amdgcn_sqrtf(fmaf(flt.oz, flt.oz, fmaf(flt.oy, flt.oy, flt.ox * flt.ox))) * 1.000001f);
+                if (best != 0x7fffffff) { // the closest wide sphere caps the search: its root as arc length from the moved origin
+                    const float sig = (float)__builtin_fma(closest, len, -s0);
+                    cd.ub = fmaf(9.5367431640625e-07f, flt.on, fmaf(2.384185791015625e-07f, fabsf(sig), sig));
+                }
+                { // the loose spheres (narrow spheres kept out of the grid): rows and list positions through scalar loads
+                    const DRAY_CONSTANT V4f* lg = as_constant((const V4f*)ka->rg.grid.loose_geom);
+                    const DRAY_CONSTANT int32_t* li = as_constant(ka->rg.grid.loose_index);
+                    const int32_t n_loose = ka->rg.grid.n_loose;
+                    bool over = false;
+                    for (int32_t q = 0; q < n_loose; ++q) {
+                        const V4f row = lg[q];
+                        over = over | filter_test(flt, row.x, row.y, row.z, row.w, (uint32_t)li[q], cd);
+                    }
+                    if (over) fallback = true; // more than two of them at once may hold the closest root: the whole list decides
+                }
+                if (!fallback && !passes_by && ka->rg.grid.n[0] > 0) { // the ray's first cell (3-D DDA along the f32 ray)
+                    const float o[3] = {flt.ox, flt.oy, flt.oz}, d[3] = {flt.ux, flt.uy, flt.uz};
+                    float t_in = 0.f, t_out = INFINITY, bmax = 0.f;
 #pragma unroll
-                    for (int a = 0; a < 3; ++a) {
-                        if (fabs(d[a]) > 1e-250) {
-                            const double inv = 1.0 / d[a];
-                            wk.A[a] = (double)ka->rg.grid.cell[a] * inv;
-                            const double t0 = ((double)ka->rg.grid.lo[a] - o[a]) * inv, t1 = ((double)ka->rg.grid.hi[a] - o[a]) * inv;
-                            wk.B[a] = d[a] >= 0. ? t0 + wk.A[a] : t0; // leaving cell k towards larger indices happens at plane k + 1
-                            t_in = fmax(t_in, fmin(t0, t1));
-                            t_out = fmin(t_out, fmax(t0, t1));
-                            bmax = fmax(bmax, fmax(fabs(t0), fabs(wk.B[a])));
+                    for (int ax = 0; ax < 3; ++ax) {
+                        if (fabsf(d[ax]) > 1e-12f) {
+                            const float inv = __builtin_amdgcn_rcpf(d[ax]);
+                            rc.A[ax] = ka->rg.grid.cell[ax] * inv;
+                            const float t0 = (ka->rg.grid.lo[ax] - o[ax]) * inv, t1 = (ka->rg.grid.hi[ax] - o[ax]) * inv;
+                            rc.B[ax] = d[ax] >= 0.f ? t0 + rc.A[ax] : t0; // leaving cell k towards larger indices happens at plane k + 1
+                            t_in = fmaxf(t_in, fminf(t0, t1));
+                            t_out = fminf(t_out, fmaxf(t0, t1));
+                            bmax = fmaxf(bmax, fmaxf(fabsf(t0), fabsf(rc.B[ax])));
                         } else { // parallel to the axis' planes: never crosses one; misses the grid if outside its slab
-                            wk.A[a] = 0.;
-                            wk.B[a] = INFINITY;
-                            if (o[a] < (double)ka->rg.grid.lo[a] || o[a] > (double)ka->rg.grid.hi[a]) inside_slabs = false;
+                            rc.A[ax] = 0.f;
+                            rc.B[ax] = INFINITY;
+                            if (o[ax] < ka->rg.grid.lo[ax] || o[ax] > ka->rg.grid.hi[ax]) t_out = -INFINITY;
                         }
                     }
-                    wk.slack = bmax * 1e-9;
-                    if (inside_slabs && t_in <= t_out + wk.slack) {
+                    rc.slack = bmax * 3.814697265625e-6f; // 2^-18 of the largest term the boundary times are formed from
+                    if (t_in <= t_out + rc.slack && !(cd.ub < t_in - rc.slack)) {
 #pragma unroll
-                        for (int a = 0; a < 3; ++a) {
-                            const double at = floor((o[a] + d[a] * t_in - (double)ka->rg.grid.lo[a]) * (double)ka->rg.grid.inv_cell[a]);
-                            wk.c[a] = (int32_t)fmin(fmax(at, 0.), (double)(ka->rg.grid.n[a] - 1));
+                        for (int ax = 0; ax < 3; ++ax) {
+                            const float at = (fmaf(d[ax], t_in, o[ax]) - ka->rg.grid.lo[ax]) * ka->rg.grid.inv_cell[ax];
+                            wk.c[ax] = fminf(fmaxf(floorf(at), 0.f), (float)(ka->rg.grid.n[ax] - 1));
                         }
+                        const uint32_t ci = (uint32_t)fmaf(fmaf(wk.c[2], (float)ka->rg.grid.n[1], wk.c[1]), (float)ka->rg.grid.n[0], wk.c[0]);
                         uint32_t unused;
-                        const uint2 cellrec = cell_of(((size_t)wk.c[2] * ka->rg.grid.n[1] + wk.c[1]) * ka->rg.grid.n[0] + wk.c[0], unused);
+                        const uint2 cellrec = cell_of(ci, unused);
                         wk.e = cellrec.x;
                         wk.e_end = cellrec.x + cellrec.y;
                         walking = true;
+                        lds_ray[wv][0][lane] = V4f{rc.A[0], rc.A[1], rc.A[2], rc.slack};
+                        lds_ray[wv][1][lane] = V4f{rc.B[0], rc.B[1], rc.B[2], flt.on};
+                        lds_ray[wv][2][lane] = V4f{flt.ox, flt.oy, flt.oz, flt.tm_lo};
+                        lds_ray[wv][3][lane] = V4f{flt.ux, flt.uy, flt.uz, flt.tm_hi};
                     }
                 }
             }
@@ -671,11 +834,11 @@ bool plan_render_f64_stream(const CamDev<double>& cam, const Partition& part, co
     plan->lds_bytes = 0;
     {
         const size_t n_cells = (size_t)scene.grid.n[0] * (size_t)scene.grid.n[1] * (size_t)scene.grid.n[2];
-        const size_t bytes = (size_t)scene.n * 32u + n_cells * 4u + ((scene.grid_entries * 2u + 15u) & ~(size_t)15u);
+        const size_t bytes = (size_t)scene.n * 16u + n_cells * 4u + ((scene.grid_entries * 2u + 15u) & ~(size_t)15u);
         const char* env = std::getenv("DRAY_GRID_LDS");
         int occ_lds = 0;
         if (!(env && env[0] == '0') && scene.n_boxes == 0 && scene.n <= 65535 && scene.grid_entries < (1u << kLds64BeginBits) &&
-            scene.grid_max_cell_entries < (1u << kLds64CountBits) && bytes <= 48 * 1024 &&
+            scene.grid_max_cell_entries < (1u << kLds64CountBits) && bytes <= 28 * 1024 && n_cells > 0 &&
             hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_lds, render_f64_stream_kernel<false, true>, 256, bytes) == hipSuccess &&
             occ_lds >= occ)
             plan->lds_bytes = bytes;
@@ -705,6 +868,23 @@ hipError_t launch_render_f64_stream(const CamDev<double>& cam, const SceneDev& s
     args.rings = (RingEntry*)rings; args.chunk_pixels = plan.chunk_pixels;
     args.n_cells = scene.grid.n[0] * scene.grid.n[1] * scene.grid.n[2];
     args.n_entries = (int32_t)scene.grid_entries;
+    args.narrow_geom = (const V4f*)scene.f32.narrow_geom;
+    args.narrow_index = scene.f32.narrow_index;
+    args.n_narrow_padded = scene.f32.n_narrow_padded;
+    { // the ball of the narrow spheres, and what the f32 search may be trusted with
+        const double radius = (double)scene.f32.bound[3];
+        double size = 0.;
+        for (int q = 0; q < 3; ++q) {
+            args.ball[q] = (double)scene.f32.bound[q];
+            size = std::fmax(size, std::fabs(args.ball[q]));
+        }
+        args.ball[3] = radius;
+        size += radius;
+        args.ball_far2 = 2.1 * radius * radius;
+        // an origin up to 2^20 scene sizes away is moved up to the ball with an error far inside the search's brackets
+        args.reach = std::isfinite(size) ? 1048576. * size : INFINITY;
+        args.filter_ok = (!std::isfinite(radius) || (size >= 1e-12 && size <= 1e12)) ? 1 : 0;
+    }
     auto launch = [&](auto kernel) {
         hipLaunchKernelGGL(kernel, dim3((unsigned)plan.grid), dim3(plan.block), plan.lds_bytes, stream, args);
     };
