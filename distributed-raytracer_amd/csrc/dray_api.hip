@@ -502,6 +502,17 @@ int scene_create_impl(const dray_sphere* sp, size_t n, int32_t device, dray_scen
         g64[4 * k + 3] = r; m64[4 * k + 3] = f;
         g32[4 * k + 3] = (float)r; m32[4 * k + 3] = (float)f;
         kind[k] = sp[k].kind;
+        if (sp[k].kind == DRAY_MAT_DIELECTRIC) {
+            // A Dialectric has no albedo (material.rs:108: attenuation (1, 1, 1)), so the first three places of its f64
+            // row hold what its scatter derives from ior alone, made here with the reference's operations (IEEE
+            // quotients and products are the same on any machine): 1 / ior (material.rs:109) and reflectance's
+            // r0 = ((1 - ri) / (1 + ri))^2 (material.rs:95-96) for ri = 1 / ior (front face) and ri = ior (back face).
+            const double inv = 1.0 / f;
+            double r0f = (1.0 - inv) / (1.0 + inv), r0b = (1.0 - f) / (1.0 + f);
+            r0f = r0f * r0f;
+            r0b = r0b * r0b;
+            m64[4 * k + 0] = inv; m64[4 * k + 1] = r0f; m64[4 * k + 2] = r0b;
+        }
     }
     classify_spheres(sp, n, ng, nidx, widx);
     d.n_narrow = (int32_t)nidx.size();

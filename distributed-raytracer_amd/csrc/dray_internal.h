@@ -74,7 +74,7 @@ struct SceneDev {
     int32_t n = 0;
     // f64 tables (reference-order kernels)
     double* geom64 = nullptr; // n x 4: cx, cy, cz, radius
-    double* mat64 = nullptr;  // n x 4: albedo rgb, fuzz or ior
+    double* mat64 = nullptr;  // n x 4: albedo rgb, fuzz or ior (a Dialectric's row: 1 / ior, r0 front, r0 back, ior)
     uint32_t* kind = nullptr; // n
     uint32_t* kind32 = nullptr; // n: the kinds as the throughput kernel takes them (see scene_create_impl)
     // f32 tables (throughput and f32-plain kernels)

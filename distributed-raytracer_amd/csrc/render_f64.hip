@@ -132,12 +132,36 @@ struct Filter32 {
 };
 constexpr uint32_t kNoCand = 0xFFFFFFFFu;
 struct Cand {
-    float ub;        // an upper bound on the closest accepted root, from spheres hit for certain (and the wide spheres' exact roots)
+    float ub;        // an upper bound on the closest accepted root, from spheres hit for certain
+    float lo0;       // a lower bound on the root of the sphere in the first slot
     uint32_t i0, i1; // list positions of the spheres that may hold the closest root (kNoCand: free slot)
 };
 
-// One sphere against the search so far.  Returns true when the sphere is a candidate and both slots are taken: the
-// caller has the slots evaluated and tests the sphere again.
+// A sphere's root brackets against the search so far: the near root lies in [near_lo, near_hi], the far root in
+// [far_lo, far_hi]; `never` -- no root for certain --, `real` -- two roots for certain.  A sphere that is hit for certain
+// lowers `ub`; the sphere in the first slot leaves it once its lower bound lies beyond `ub` -- its root is then farther
+// than another sphere's --, so that a ray nearly always ends its search with one sphere to take the reference's test, and
+// the second slot is for roots the brackets cannot tell apart.  Returns true when the sphere is a candidate and both
+// slots are taken: the caller has the slots evaluated and tests the sphere again.
+__device__ __forceinline__ bool slot_update(float tm_lo, float tm_hi, float near_lo, float near_hi, float far_lo, float far_hi,
+                                            bool never, bool real, uint32_t k, Cand& c) {
+    const bool miss = never | (far_hi < tm_lo);
+    const float lo = near_hi < tm_lo ? far_lo : near_lo;
+    const bool sure_near = near_lo > tm_hi;
+    const bool certain = real & (sure_near | (far_lo > tm_hi));
+    const float hi = sure_near ? near_hi : far_hi;
+    // a sphere met again (it is listed in several cells) is not taken twice
+    const bool keep = !miss & !(lo > c.ub) & (k != c.i0) & (k != c.i1);
+    c.ub = (certain & keep & (hi < c.ub)) ? hi : c.ub;
+    const bool take0 = keep & ((c.i0 == kNoCand) | (c.lo0 > c.ub)); // a free slot, or one whose sphere has just fallen behind
+    const bool free1 = c.i1 == kNoCand;
+    c.i1 = (keep & !take0 & free1) ? k : c.i1;
+    c.i0 = take0 ? k : c.i0;
+    c.lo0 = take0 ? lo : c.lo0;
+    return keep & !take0 & !free1;
+}
+
+// One narrow sphere against the search so far.
 __device__ __forceinline__ bool filter_test(const Filter32& f, float cx, float cy, float cz, float r2, uint32_t k, Cand& c) {
     const float ocx = cx - f.ox, ocy = cy - f.oy, ocz = cz - f.oz;
     const float h = fmaf(ocz, f.uz, fmaf(ocy, f.uy, ocx * f.ux));
@@ -149,20 +173,39 @@ __device__ __forceinline__ bool filter_test(const Filter32& f, float cx, float c
     const float dhi = disc + e, dlo = disc - e;
     const float sq_hi = __builtin_amdgcn_sqrtf(fmaxf(dhi, 0.f)), sq_lo = __builtin_amdgcn_sqrtf(fmaxf(dlo, 0.f));
     const float eh = fmaf(9.5367431640625e-07f, ocn + f.on + sq_hi, 1e-15f);
-    const float near_lo = (h - sq_hi) - eh, near_hi = (h - sq_lo) + eh;
-    const float far_lo = (h + sq_lo) - eh, far_hi = (h + sq_hi) + eh;
-    const bool miss = (dhi < 0.f) | (far_hi < f.tm_lo);
-    const float lo = near_hi < f.tm_lo ? far_lo : near_lo;
-    const bool sure_near = near_lo > f.tm_hi;
-    const bool certain = (dlo > 0.f) & (sure_near | (far_lo > f.tm_hi));
-    const float hi = sure_near ? near_hi : far_hi;
-    // a sphere met again (it is listed in several cells) is not taken twice
-    const bool keep = !miss & !(lo > c.ub) & (k != c.i0) & (k != c.i1);
-    c.ub = (certain & keep & (hi < c.ub)) ? hi : c.ub;
-    const bool free0 = c.i0 == kNoCand, free1 = c.i1 == kNoCand;
-    c.i1 = (keep & !free0 & free1) ? k : c.i1;
-    c.i0 = (keep & free0) ? k : c.i0;
-    return keep & !free0 & !free1;
+    return slot_update(f.tm_lo, f.tm_hi, (h - sq_hi) - eh, (h - sq_lo) + eh, (h + sq_lo) - eh, (h + sq_hi) + eh, dhi < 0.f, dlo > 0.f, k, c);
+}
+
+// One wide sphere: in f32 its |oc|^2 - r^2 cancels, and a bracket as wide as f32 leaves it could not tell the root 0 of
+// a ray that starts on the sphere from the reference's lower bound.  So oc, h = oc.u, disc = h^2 + r^2 - |oc|^2, its
+// square root (v_rsq_f64 and one Newton step) and the two roots h -+ sqrt are formed in f64, from the ray as the
+// reference has it -- origin `ro`, the unit direction `u` (good to 2^-40), roots counted from the f32 view's origin, `s0`
+// along the ray -- and rounded to f32 at the end.  Errors: u's 2^-40 and the f64 roundings leave disc within
+// E = 2^-36 (|oc|^2 + r^2) of the true value (the reference's own discriminant within 2^-48 of the same), which moves
+// the square root by at most E / max(sqrt, sqrt E); h and the sums are good to 2^-36 (|oc| + sqrt); rounding a root to
+// f32 adds 2^-24 of its size, and 2^-20 |o~| is the narrow spheres' allowance for the rounded origin.
+__device__ __forceinline__ bool wide_test(float tm_lo, float tm_hi, float on, V3<double> ro, V3<double> u, double s0, double cx,
+                                          double cy, double cz, double radius, uint32_t k, Cand& c) {
+    const double ocx = cx - ro.x, ocy = cy - ro.y, ocz = cz - ro.z;
+    const double h = __builtin_fma(ocz, u.z, __builtin_fma(ocy, u.y, ocx * u.x));
+    const double oc2 = __builtin_fma(ocz, ocz, __builtin_fma(ocy, ocy, ocx * ocx));
+    const double r2 = radius * radius;
+    const double disc = __builtin_fma(h, h, r2 - oc2);
+    const double dpos = fmax(disc, 1e-300);
+    const double y = __builtin_amdgcn_rsq(dpos);
+    double sq = dpos * y;
+    sq = __builtin_fma(__builtin_fma(-sq, sq, dpos), 0.5 * y, sq);
+    const double hs = h - s0;
+    const float near = (float)(hs - sq), far = (float)(hs + sq);
+    const float size2 = (float)(oc2 + r2), sqf = (float)sq;
+    const float e = fmaf(1.4551915228366852e-11f, size2, 1e-37f); // E
+    const float se = __builtin_amdgcn_sqrtf(e);
+    const float dsq = e * __builtin_amdgcn_rcpf(fmaxf(sqf, se)) * 1.0001f;
+    const float size = __builtin_amdgcn_sqrtf(size2);
+    const float eps = fmaf(9.5367431640625e-07f, on, fmaf(1.4551915228366852e-11f, size + sqf, dsq));
+    const float en = fmaf(1.1920928955078125e-07f, fabsf(near), eps), ef = fmaf(1.1920928955078125e-07f, fabsf(far), eps);
+    const float disc_f = (float)disc;
+    return slot_update(tm_lo, tm_hi, near - en, near + en, far - ef, far + ef, disc_f < -e, disc_f > e * 1.0001f + fabsf(disc_f) * 1.1920928955078125e-07f, k, c);
 }
 
 // A lane's walk through the grid (3-D DDA along the f32 ray), kept across turns of the main loop.  Boundary times are
@@ -358,7 +401,7 @@ void render_f64_stream_kernel(F64Args) {
     bool dead = false;     // the path was absorbed: the sample ends black at the lane's next turn
     bool fallback = false; // the closest hit of this ray comes from the scan of the whole list
     Walk32 wk = {};
-    Cand cd = {INFINITY, kNoCand, kNoCand};
+    Cand cd = {INFINITY, INFINITY, kNoCand, kNoCand};
     double closest = INFINITY; // smallest root the reference's test has accepted so far, and its sphere's list position
     int32_t best = 0x7fffffff;
 
@@ -515,13 +558,15 @@ void render_f64_stream_kernel(F64Args) {
                 paused = false;
             }
         }
-        // ---- lanes whose walk is over: the hit (hittable_list.rs:60-74 / sphere.rs:49-55), or the sky -----------
-        // (which sphere or box and how far is all that is settled here; point and normal are made where the scatter
-        // needs them, after the wave's draws, so that they do not sit in registers through those)
+        // ---- lanes whose walk is over: the hit (hittable_list.rs:60-74), or the sky, or the end of the path ----------
+        // Which sphere or box and how far is all that is settled here.  Point and normal, the scatter, the sky's colour and
+        // the sample's product are made after the wave's draws: none of them sits in registers through those, and the
+        // square roots and divisions of the sky and of the materials are then one piece of code (see below).  A lane
+        // whose sample ends is free for the next one at once; `end_item` keeps the ended sample's place in the ring.
         const bool ready = has && !walking && !camera;
-        bool scatters = false, ended = false, is_box = false;
+        bool scatters = false, ended = false, sky = false, is_box = false;
         uint32_t mk = 0xFFu;
-        V3<double> c = {0., 0., 0.};
+        const uint32_t end_item = item;
         if (ready) {
             if (depth <= 0 || dead) { // camera.rs:265-267 / :120-123, or absorbed (camera.rs:276): black
                 ended = true;
@@ -542,42 +587,17 @@ void render_f64_stream_kernel(F64Args) {
                     mk = ka->kind[best];
                     scatters = true;
                 } else {
-                    V3<double> ud = vunit(rd); // camera.rs:279-281
-                    double a = 0.5 * (ud.y + 1.0);
-                    c = vadd(vscale(V3<double>{1.0, 1.0, 1.0}, 1.0 - a), vscale(V3<double>{0.5, 0.7, 1.0}, a));
-                    ended = true;
+                    ended = sky = true; // camera.rs:279-281
                 }
+            }
+            if (ended) {
+                dead = false;
+                has = false;
             }
         }
 
         F64_CLOCK(1);
         F64_COUNT(20, __popcll(__ballot(ready)));      // lanes shading
-        // ---- samples that end here: their colour goes to its place in the wave's ring ---------------------------
-        if (ended) {
-            if constexpr (iterative) {
-                c = vmul(att, c); // camera.rs:121,135,142
-            } else {
-                while (sp > 0) { // camera.rs:274, innermost product first; four albedos are fetched at a time
-                    const int32_t n4 = sp < 4 ? sp : 4;
-                    uint32_t q[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) q[u] = stack[sp - 1 - (u < n4 ? u : 0)];
-                    V3<double> al[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) al[u] = {ka->mat[4 * q[u]], ka->mat[4 * q[u] + 1], ka->mat[4 * q[u] + 2]};
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                        if (u < n4) c = vmul(al[u], c);
-                    sp -= n4;
-                }
-            }
-            RingEntry* e = ring + (item & (kF64RingEntries - 1u));
-            e->rg = D2{0. + c.x, 0. + c.y}; // camera.rs:223-225: pixel_color = (0, 0, 0) + sample
-            e->b = 0. + c.z;
-            dead = false;
-            has = false;
-        }
-
         F64_CLOCK(2);
         // ---- refill: free lanes take the next samples of the stream (camera.rs:217-224) ------------------------
         {
@@ -638,38 +658,132 @@ void render_f64_stream_kernel(F64Args) {
         const Drawn got = coop_draw64(st, w, draw, lds_req, lane);
         F64_CLOCK(6);
 
-        // ---- scatter: material.rs -------------------------------------------------------------------------
+        // ---- scatter (material.rs) and sky (camera.rs:279-281) ---------------------------------------------
+        // Every operation is the reference's, in the reference's order, lane by lane; what is shared is the code.  A
+        // wave nearly always holds lanes of every kind at once, so each IEEE square root and each division by a common
+        // divisor that the kinds need is written once, for whichever lanes need it at that point:
+        //   first normalisation  v / sqrt(|v|^2): the sky's and the Dialectric's unit direction (vec3.rs:120-122), the
+        //                        Lambertian's random unit vector (vec3.rs:82), the Metal's unit reflection (material.rs:75);
+        //   second square root:  the Metal's random unit vector (then divided through), the Dialectric's sin_theta
+        //                        (material.rs:109);
+        //   third square root:   refract's parallel part (vec3.rs:107).
         bool fresh = false;
-        if (scatters) {
-            Hit<double> rec; // sphere.rs:49-55
-            if (is_box) box_record<double>(ro, rd, closest, best, rec);
-            else fill_hit<double>(ka->geom, best, ro, rd, closest, rec);
-            V3<double> so = ro, sd;
-            const bool scattered = scatter_with<double>(
-                mk, ka->mat + 4 * rec.index, rd, rec,
-                [&]() { // vec3.rs:82 for the accepted attempt
-                    const uint32_t ww[4] = {got.a, got.b, got.c, 0u};
-                    V3<double> p;
-                    double lensq;
-                    unit_vector_attempt<double>(ww, p, lensq);
-                    return vdiv(p, vsqrt(lensq));
-                },
-                [&]() { return u01<double>(w[0]); }, so, sd);
-            if (scattered) {
-                const bool white = mk == DRAY_MAT_DIELECTRIC || mk == DRAY_MAT_TRANSPARENT; // attenuation (1, 1, 1)
-                if constexpr (iterative) {
-                    V3<double> al = white ? V3<double>{1., 1., 1.}
-                                          : V3<double>{ka->mat[4 * rec.index], ka->mat[4 * rec.index + 1], ka->mat[4 * rec.index + 2]};
-                    att = vmul(att, al); // camera.rs:130
-                } else if (!white) {
-                    stack[sp++] = (uint32_t)rec.index; // a product with (1,1,1) is exact, so those are skipped
+        {
+            const bool lam = scatters && mk == DRAY_MAT_LAMBERTIAN, met = scatters && mk == DRAY_MAT_METAL;
+            const bool die = scatters && mk == DRAY_MAT_DIELECTRIC;
+            Hit<double> rec = {}; // sphere.rs:49-55
+            if (scatters) {
+                if (is_box) box_record<double>(ro, rd, closest, best, rec);
+                else fill_hit<double>(ka->geom, best, ro, rd, closest, rec);
+            }
+            const D2* mrow = (const D2*)(ka->mat + 4 * (size_t)(scatters ? rec.index : 0));
+            D2 m01 = {0., 0.}, m23 = {0., 0.};
+            if (met || die) { m01 = mrow[0]; m23 = mrow[1]; }
+            V3<double> pr = {0., 0., 0.}; // the accepted attempt's point in the cube (vec3.rs:78)
+            double lensq = 1.;
+            if (lam || met) {
+                const uint32_t ww[4] = {got.a, got.b, got.c, 0u};
+                unit_vector_attempt<double>(ww, pr, lensq);
+            }
+            // first normalisation
+            V3<double> va = rd;
+            if (lam) va = pr;
+            if (met) va = reflect(rd, rec.normal); // material.rs:74
+            V3<double> ua = {0., 0., 0.};
+            if (sky || lam || met || die) ua = vdiv(va, vsqrt(vlen2(va)));
+            // what each kind makes of it, up to its next square root
+            V3<double> sd = rd, so = ro; // Transparent (material.rs:25-31): the incoming ray, unchanged
+            bool scattered = scatters && (mk == DRAY_MAT_TRANSPARENT);
+            double cos_theta = 0., ri = 1., x2nd = 1.;
+            if (scatters && mk != DRAY_MAT_TRANSPARENT) so = rec.p;
+            if (lam) { // material.rs:46-56
+                V3<double> dir = vadd(rec.normal, ua);
+                const double tiny = 1e-8; // vec3.rs:42-45
+                if (fabs(dir.x) < tiny && fabs(dir.y) < tiny && fabs(dir.z) < tiny) dir = rec.normal;
+                sd = dir;
+                scattered = true;
+            }
+            if (met) x2nd = lensq;
+            if (die) { // material.rs:103-109; the table holds 1 / ior beside ior (an IEEE quotient is the same wherever it is made)
+                ri = rec.front_face ? m01.x : m23.y;
+                cos_theta = fmin(vdot(vneg(ua), rec.normal), 1.0);
+                x2nd = 1.0 - cos_theta * cos_theta;
+            }
+            // second square root
+            double s2nd = 0.;
+            if (met || die) s2nd = vsqrt(x2nd);
+            if (met) { // material.rs:75-80
+                const V3<double> uv = vdiv(pr, s2nd);
+                sd = vadd(ua, vscale(uv, m23.y));
+                scattered = vdot(sd, rec.normal) > 0.;
+            }
+            bool refracts = false;
+            V3<double> perp = {0., 0., 0.};
+            if (die) { // material.rs:110-121
+                bool reflects = ri * s2nd > 1.0;
+                if (!reflects) { // the uniform is drawn only when refraction is possible
+                    // material.rs:93-98; r0 = ((1 - ri) / (1 + ri))^2 comes from the table, for the face that was hit
+                    const double r0 = rec.front_face ? m01.y : m23.x;
+                    const double x = 1.0 - cos_theta;
+                    const double xx = x * x;
+                    const double x5 = x * (xx * xx); // powi(5)
+                    reflects = r0 + (1.0 - r0) * x5 > u01<double>(w[0]);
                 }
-                ro = so;
-                rd = sd;
-                depth -= 1;
-                fresh = depth > 0; // with no depth left the sample ends black at the lane's next turn
-            } else {
-                dead = true; // camera.rs:276
+                refracts = !reflects;
+                if (reflects) sd = reflect(ua, rec.normal);
+                else perp = vscale(vadd(ua, vscale(rec.normal, cos_theta)), ri); // vec3.rs:105-106 (the same cosine)
+                scattered = true;
+            }
+            // third square root
+            if (refracts) {
+                const double k = -(vsqrt(fabs(1.0 - vlen2(perp)))); // vec3.rs:107
+                sd = vadd(perp, vscale(rec.normal, k));
+            }
+            if (scatters) {
+                if (scattered) {
+                    const bool white = mk == DRAY_MAT_DIELECTRIC || mk == DRAY_MAT_TRANSPARENT; // attenuation (1, 1, 1)
+                    if constexpr (iterative) {
+                        V3<double> al = white ? V3<double>{1., 1., 1.}
+                                              : V3<double>{ka->mat[4 * rec.index], ka->mat[4 * rec.index + 1], ka->mat[4 * rec.index + 2]};
+                        att = vmul(att, al); // camera.rs:130
+                    } else if (!white) {
+                        stack[sp++] = (uint32_t)rec.index; // a product with (1,1,1) is exact, so those are skipped
+                    }
+                    ro = so;
+                    rd = sd;
+                    depth -= 1;
+                    fresh = depth > 0; // with no depth left the sample ends black at the lane's next turn
+                } else {
+                    dead = true; // camera.rs:276
+                }
+            }
+            // ---- samples that end here: their colour goes to its place in the wave's ring ---------------------------
+            if (ended) {
+                V3<double> c = {0., 0., 0.};
+                if (sky) {
+                    const double a = 0.5 * (ua.y + 1.0);
+                    c = vadd(vscale(V3<double>{1.0, 1.0, 1.0}, 1.0 - a), vscale(V3<double>{0.5, 0.7, 1.0}, a));
+                }
+                if constexpr (iterative) {
+                    c = vmul(att, c); // camera.rs:121,135,142
+                } else {
+                    while (sp > 0) { // camera.rs:274, innermost product first; four albedos are fetched at a time
+                        const int32_t n4 = sp < 4 ? sp : 4;
+                        uint32_t q[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) q[u] = stack[sp - 1 - (u < n4 ? u : 0)];
+                        V3<double> al[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) al[u] = {ka->mat[4 * q[u]], ka->mat[4 * q[u] + 1], ka->mat[4 * q[u] + 2]};
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            if (u < n4) c = vmul(al[u], c);
+                        sp -= n4;
+                    }
+                }
+                RingEntry* e = ring + (end_item & (kF64RingEntries - 1u));
+                e->rg = D2{0. + c.x, 0. + c.y}; // camera.rs:223-225: pixel_color = (0, 0, 0) + sample
+                e->b = 0. + c.z;
             }
         }
 
@@ -693,7 +807,7 @@ void render_f64_stream_kernel(F64Args) {
             my_segments++;
             closest = INFINITY;
             best = 0x7fffffff;
-            cd = {INFINITY, kNoCand, kNoCand};
+            cd = {INFINITY, INFINITY, kNoCand, kNoCand};
             wk.e = wk.e_end = 0u;
             walking = false;
             paused = false;
@@ -705,13 +819,6 @@ void render_f64_stream_kernel(F64Args) {
             fallback = !(omax <= ka->reach && fabs(rd.x) < 1e300 && fabs(rd.y) < 1e300 && fabs(rd.z) < 1e300 && a >= 1e-200 &&
                          a <= 1e200 && ka->filter_ok != 0);
             if (!fallback) {
-                { // the wide spheres take the reference's test at once (scalar loads): in f32 their |oc|^2 - r^2 cancels
-                    const DRAY_CONSTANT double* ag = as_constant(ka->rg.always_geom64);
-                    const DRAY_CONSTANT int32_t* ai = as_constant(ka->rg.always_index);
-                    const int32_t n_wide = ka->rg.n_wide;
-                    for (int32_t q = 0; q < n_wide; ++q)
-                        exact_test(V3<double>{ag[4 * q], ag[4 * q + 1], ag[4 * q + 2]}, ag[4 * q + 3], ai[q], ro, rd, closest, best);
-                }
                 // unit direction (v_rsq_f64 is good to 2^-23; one Newton step makes it 2^-40), and the origin moved along
                 // the ray up to the ball of the narrow spheres
                 double il = __builtin_amdgcn_rsq(a);
@@ -732,15 +839,18 @@ void render_f64_stream_kernel(F64Args) {
                 flt.tm_lo = fmaf(-4.76837158203125e-07f, fabsf(tm), tm);
                 flt.tm_hi = fmaf(4.76837158203125e-07f, fabsf(tm), tm);
                 flt.on = fmaf(0.001953125f, (float)s0, __builtin_amdgcn_sqrtf(fmaf(flt.oz, flt.oz, fmaf(flt.oy, flt.oy, flt.ox * flt.ox))) * 1.000001f);
-                if (best != 0x7fffffff) { // the closest wide sphere caps the search: its root as arc length from the moved origin
-                    const float sig = (float)__builtin_fma(closest, len, -s0);
-                    cd.ub = fmaf(9.5367431640625e-07f, flt.on, fmaf(2.384185791015625e-07f, fabsf(sig), sig));
-                }
-                { // the loose spheres (narrow spheres kept out of the grid): rows and list positions through scalar loads
+                { // the spheres every ray meets, rows and list positions through scalar loads: the wide ones (their
+                  // |oc|^2 - r^2 cancels in f32: bracketed from f64 values), then the loose ones (narrow spheres kept out of the grid)
+                    bool over = false;
+                    const DRAY_CONSTANT double* ag = as_constant(ka->rg.always_geom64);
+                    const DRAY_CONSTANT int32_t* ai = as_constant(ka->rg.always_index);
+                    const int32_t n_wide = ka->rg.n_wide;
+                    for (int32_t q = 0; q < n_wide; ++q)
+                        over = over | wide_test(flt.tm_lo, flt.tm_hi, flt.on, ro, u, s0, ag[4 * q], ag[4 * q + 1], ag[4 * q + 2], ag[4 * q + 3],
+                                                (uint32_t)ai[q], cd);
                     const DRAY_CONSTANT V4f* lg = as_constant((const V4f*)ka->rg.grid.loose_geom);
                     const DRAY_CONSTANT int32_t* li = as_constant(ka->rg.grid.loose_index);
                     const int32_t n_loose = ka->rg.grid.n_loose;
-                    bool over = false;
                     for (int32_t q = 0; q < n_loose; ++q) {
                         const V4f row = lg[q];
                         over = over | filter_test(flt, row.x, row.y, row.z, row.w, (uint32_t)li[q], cd);
