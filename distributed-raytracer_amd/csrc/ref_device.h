@@ -46,9 +46,13 @@ __device__ __forceinline__ double div_by(double x, double s, double y) { // x / 
     const double e = __builtin_fma(-s, q0, x);
     return __builtin_fma(e, y, q0);
 }
+__device__ __forceinline__ bool div_band4(double a, double b, double c, double d) { // all four in the band (no branches)
+    auto off = [](double x) { return (((uint32_t)__double2hiint(x) >> 20) & 0x7ffu) - 700u; };
+    return max(max(off(a), off(b)), max(off(c), off(d))) <= 650u;
+}
 template <typename T> __device__ __forceinline__ V3<T> vdiv(V3<T> a, T s) {
     if constexpr (sizeof(T) == sizeof(double)) {
-        if (div_band(s) && div_band(a.x) && div_band(a.y) && div_band(a.z)) {
+        if (div_band4(s, a.x, a.y, a.z)) {
             const double y = refined_rcp(s);
             return {div_by(a.x, s, y), div_by(a.y, s, y), div_by(a.z, s, y)};
         }

@@ -60,18 +60,45 @@ struct Drawn {
     uint32_t a, b, c; // the accepted attempt's words: a unit vector's three, or a disk point's two
 };
 
+// Whether the reference keeps an attempt of its rejection samplers, decided in f32 wherever f32 can tell.  An attempt's
+// coordinates are -1 + 2 u with u = k 2^-24, exact in f32 as in f64, and the f64 sum of their squares is exact too
+// (integers below 2^49 in units of 2^-46), so the reference's comparisons (vec3.rs:80: 1e-160 <= |p|^2 <= 1; vec3.rs:114:
+// |p|^2 < 1) are comparisons of the true sum, which the f32 sum misses by at most 2^-22 of itself.  `unsure`: the f32 sum is
+// too close to a bound to tell (one attempt in some 10^6); the caller then has the f64 expressions decide.
+__device__ __forceinline__ bool vector_kept_f32(uint32_t w0, uint32_t w1, uint32_t w2, bool& unsure) {
+    const float x = fmaf(2.f, u01<float>(w0), -1.f), y = fmaf(2.f, u01<float>(w1), -1.f), z = fmaf(2.f, u01<float>(w2), -1.f);
+    const float l2 = fmaf(z, z, fmaf(y, y, x * x));
+    unsure = (fabsf(l2 - 1.f) < 1e-6f) | (l2 < 1e-12f);
+    return l2 <= 1.f;
+}
+__device__ __forceinline__ bool disk_kept_f32(uint32_t w0, uint32_t w1, bool& unsure) {
+    const float x = fmaf(2.f, u01<float>(w0), -1.f), y = fmaf(2.f, u01<float>(w1), -1.f);
+    const float l2 = fmaf(y, y, x * x);
+    unsure = fabsf(l2 - 1.f) < 1e-6f;
+    return l2 < 1.f;
+}
+
 // Both rejection samplers for all lanes of a wave (wave-uniform control flow; every lane calls).  `w` is block 0 of
-// the lane's stream, `draw` what the lane needs.  Acceptance is decided in f64 with the reference's expressions.
+// the lane's stream, `draw` what the lane needs.  Acceptance is the reference's (see above): the f64 expressions decide
+// whenever f32 cannot.
 __device__ __forceinline__ Drawn coop_draw64(const Stream& st, const uint32_t (&w)[4], uint32_t draw, uint4* req, int lane) {
     Drawn res = {w[0], w[1], w[2]};
     bool pending = false;
-    V3<double> p;
-    double l2, qx, qy;
-    if (draw == kDraw64UnitVector) {
-        pending = !unit_vector_attempt<double>(w, p, l2);
-    } else if (draw == kDraw64UnitDisk) { // attempt 0 of the aperture sample: uniforms 2, 3 of stage 0
-        res = {w[2], w[3], 0u};
-        pending = !unit_disk_attempt<double>(w[2], w[3], qx, qy);
+    {
+        bool unsure_v, unsure_d;
+        const bool kept_v = vector_kept_f32(w[0], w[1], w[2], unsure_v), kept_d = disk_kept_f32(w[2], w[3], unsure_d);
+        if (draw == kDraw64UnitVector) {
+            pending = !kept_v;
+        } else if (draw == kDraw64UnitDisk) { // attempt 0 of the aperture sample: uniforms 2, 3 of stage 0
+            res = {w[2], w[3], 0u};
+            pending = !kept_d;
+        }
+        if (__ballot((draw == kDraw64UnitVector && unsure_v) || (draw == kDraw64UnitDisk && unsure_d)) != 0ull) {
+            V3<double> p;
+            double l2, qx, qy;
+            if (draw == kDraw64UnitVector) pending = !unit_vector_attempt<double>(w, p, l2);
+            else if (draw == kDraw64UnitDisk) pending = !unit_disk_attempt<double>(w[2], w[3], qx, qy);
+        }
     }
     uint32_t base = 1u; // next block index, the same for every pending lane
     for (unsigned long long pm = __ballot(pending); pm != 0ull; pm = __ballot(pending)) {
@@ -85,10 +112,18 @@ __device__ __forceinline__ Drawn coop_draw64(const Stream& st, const uint32_t (&
         const Stream other = {st.k0, st.k1, r.x, r.y, r.z};
         uint32_t wb[4];
         other.block(base + ((uint32_t)lane & ((1u << shift) - 1u)), wb);
-        const bool ok_vector = unit_vector_attempt<double>(wb, p, l2);
-        // a block after the first holds two aperture attempts: uniforms 4b, 4b+1 and 4b+2, 4b+3
-        const bool ok_a = unit_disk_attempt<double>(wb[0], wb[1], qx, qy), ok_b = unit_disk_attempt<double>(wb[2], wb[3], qx, qy);
         const bool disk = r.w == kDraw64UnitDisk;
+        bool unsure_v, unsure_a, unsure_b;
+        bool ok_vector = vector_kept_f32(wb[0], wb[1], wb[2], unsure_v);
+        // a block after the first holds two aperture attempts: uniforms 4b, 4b+1 and 4b+2, 4b+3
+        bool ok_a = disk_kept_f32(wb[0], wb[1], unsure_a), ok_b = disk_kept_f32(wb[2], wb[3], unsure_b);
+        if (__ballot(serving && (disk ? (unsure_a || unsure_b) : unsure_v)) != 0ull) {
+            V3<double> p;
+            double l2, qx, qy;
+            ok_vector = unit_vector_attempt<double>(wb, p, l2);
+            ok_a = unit_disk_attempt<double>(wb[0], wb[1], qx, qy);
+            ok_b = unit_disk_attempt<double>(wb[2], wb[3], qx, qy);
+        }
         const uint32_t va = disk ? (ok_a ? wb[0] : wb[2]) : wb[0], vb = disk ? (ok_a ? wb[1] : wb[3]) : wb[1], vc = wb[2];
         const bool ok = serving & (disk ? (ok_a | ok_b) : ok_vector);
         const unsigned long long okm = __ballot(ok);
