@@ -137,7 +137,10 @@ hipError_t launch_render_ref_f64(const CamDev<double>& cam, const SceneDev& scen
                                  int32_t* d_count, DeviceCounters* d_counters, hipStream_t stream);
 // The f64 render as a stream of samples: one persistent launch whose waves keep finished samples in rings of
 // kF64RingEntries 32-byte entries each until they join their pixel's sum in sample order.
-constexpr uint32_t kF64RingEntries = 2048;
+#ifndef DRAY_F64_RING
+#define DRAY_F64_RING 2048
+#endif
+constexpr uint32_t kF64RingEntries = DRAY_F64_RING;
 struct F64StreamPlan {
     int32_t grid, block;   // resident blocks of the persistent launch
     size_t ring_bytes;     // one ring per wave of the launch
