@@ -861,11 +861,13 @@ struct RenderJob {
             if (space->free_after) HIP_TRY(hipStreamWaitEvent(trace_stream, space->free_after, 0)); // its last user has read the sums
         }
         HIP_TRY(hipMemsetAsync(d_counters, 0, sizeof(DeviceCounters), trace_stream));
-        HIP_TRY(hipMemsetAsync(d_accum, 0, plan.accum_words * sizeof(unsigned long long), trace_stream));
         HIP_TRY(hipEventRecord(slot->ev[0], trace_stream));
         const RngKey key = {(uint32_t)opts.seed, (uint32_t)(opts.seed >> 32), opts.sample_offset};
-        if (cam->max_depth > 0) // camera.rs:265: with no depth every sample is black and no ray is traced
+        // The trace kernel stores every pixel's sums once (render_f32.hip), so the planes are not cleared for it.
+        if (cam->max_depth > 0)
             HIP_TRY(launch_render_f32(c, scene->dev, part, key, plan, d_accum, d_counters, trace_stream));
+        else // camera.rs:265: with no depth every sample is black and no ray is traced
+            HIP_TRY(hipMemsetAsync(d_accum, 0, plan.accum_words * sizeof(unsigned long long), trace_stream));
         HIP_TRY(hipEventRecord(slot->ev[1], trace_stream));
         if (trace_stream != stream) HIP_TRY(hipStreamWaitEvent(stream, slot->ev[1], 0));
         return DRAY_OK;

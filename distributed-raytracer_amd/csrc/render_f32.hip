@@ -572,8 +572,8 @@ __device__ __forceinline__ void render_f32_body() {
     // A wave takes whole pixels from the global queue (a pool = all samples of `pixels_per_pool` consecutive
     // pixels) and hands the samples to its lanes one at a time, so the samples of a pixel finish in one wave.
     // Their fixed-point sums meet in a wave-private LDS cache (the wave's pixels take its kSlots slots in turn)
-    // and go to memory once, when the slot is given to a later pixel; a sample that ends after its pixel has left
-    // the cache adds to memory directly.  Integer sums: the image is the same whatever the grouping.  LDS keeps
+    // and go to memory once, as a plain store, when the slot is given to a later pixel; a sample that ends after its
+    // pixel has left the cache adds to memory directly (an atomic on top of that store).  Integer sums: the image is the same whatever the grouping.  LDS keeps
     // one wave's accesses in order, and tags and sums are only ever touched by their own wave: no barrier.
     __shared__ unsigned long long lds_sum[4][kSlots][3]; // [wave of the block][slot][r, g, b]
     __shared__ uint32_t lds_tag[4][kSlots];              // the slot's pixel: its Philox pixel word (j * W + i)
@@ -607,7 +607,9 @@ __device__ __forceinline__ void render_f32_body() {
                 for (int c = 0; c < 3; ++c) {
                     const unsigned long long v = __hip_atomic_exchange(&lds_sum[wv][slot][c], 0ull, __ATOMIC_RELAXED,
                                                                        __HIP_MEMORY_SCOPE_WORKGROUP);
-                    if (v != 0ull) atomicAdd(&a->accum[(size_t)c * pixel_count() + at], v); // colors.rs:38, order-free
+                    // A pixel's sums leave the cache once, here, as a plain store -- also when they are zero --, so the
+                    // planes need no clearing before a launch: every pixel of the partition is written exactly once.
+                    a->accum[(size_t)c * pixel_count() + at] = v;
                 }
             }
             __hip_atomic_store(&lds_tag[wv][slot], retag ? image_pixel_of(first_pixel + (uint32_t)lane) : kNoPixel,
@@ -624,7 +626,10 @@ __device__ __forceinline__ void render_f32_body() {
             __hip_atomic_fetch_add(&lds_sum[wv][slot][1], fg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             __hip_atomic_fetch_add(&lds_sum[wv][slot][2], fb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         } else {
+            // the pixel has left the cache: its sums are in memory, stored by a lane of this wave.  That store must
+            // have been performed before this addition is: the fence waits for the wave's outstanding stores.
             const uint32_t at = partition_index(pixel_word), npix = pixel_count();
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             atomicAdd(&a->accum[at], fr);
             atomicAdd(&a->accum[(size_t)npix + at], fg);
             atomicAdd(&a->accum[2 * (size_t)npix + at], fb);
