@@ -10,13 +10,17 @@ the 8-bit image, and for N > 1 the slabs are all-gathered over RCCL.  A ray is o
 (one closest-hit query over the whole sphere list).  Rank 0 prints one JSON line.
 
 The roofline block describes the kernel that is timed.  The default scan walks a uniform grid, so the
-work it executes is not the reference's 18 x spheres FLOP per segment; what bounds it is the vector
-ALU's issue slots.  `roofline.achieved` is therefore the kernel's executed vector instructions per
-launch (SQ_INSTS_VALU of a committed counter pass over this very command, profiles/counters.json)
-x 128 FLOP -- what one wave64 issue slot is worth at the FP32 peak -- over the launch's duration,
-which is measured live with HIP events on the launch stream.  The 18 x spheres x segments figure of
-the reference's linear scan is reported for the brute-force kernel (`roofline_bruteforce`, which
-executes every test) and, for the grid kernel, under `reference_equivalent` only.
+work it executes is not the reference's 18 x spheres FLOP per segment.  `roofline.achieved` / `frac` are
+the FP32 arithmetic the kernel executes -- the FMA (2 FLOP), add, multiply and transcendental instruction
+counters x 64 lanes x the active-lane share, from a committed counter pass over this very command
+(profiles/counters.json) -- over the launch's duration, which is measured live with HIP events on the
+launch stream, against the FP32 vector peak.  Most of a path tracer's instructions are compares, selects,
+moves and integer work, so beside it stands the share of the vector unit's issue slots the kernel fills
+(`valu_issue_frac`: executed vector instructions x 128 FLOP-equivalents per wave64 slot).  When the
+committed counters were taken on other kernel sources than the ones being run, every counter-derived
+field is null.  The 18 x spheres x segments figure of the reference's linear scan is reported for the
+brute-force kernel (`roofline_bruteforce`, which executes every test) and, for the grid kernel, under
+`reference_equivalent` only.
 """
 import argparse
 import hashlib
@@ -106,6 +110,11 @@ def executed_roofline(cnt, current, cfile, kernel_name, k_s, peak, f64=False):
     lanes = None
     if cnt.get("SQ_THREAD_CYCLES_VALU") and cnt.get("SQ_ACTIVE_INST_VALU"):
         lanes = cnt["SQ_THREAD_CYCLES_VALU"] / (64.0 * cnt["SQ_ACTIVE_INST_VALU"])
+    if not current:
+        # counters of other kernel sources say nothing about this run: only the duration stands
+        out["note"] = ("the committed counter pass was taken on other kernel sources than these: the counter-derived fields "
+                       "are left empty")
+        return out
     if f64:
         # executed f64 arithmetic: an f64 FMA is 2 FLOP per lane; masked lanes are taken out with the lane share
         flop = 64.0 * (2.0 * cnt.get("SQ_INSTS_VALU_FMA_F64", 0.0) + cnt.get("SQ_INSTS_VALU_ADD_F64", 0.0) +
@@ -113,29 +122,31 @@ def executed_roofline(cnt, current, cfile, kernel_name, k_s, peak, f64=False):
         out["achieved"] = flop / k_s / 1e12
         out["work"] = ("executed f64 FLOP per launch = 64 x (2 x SQ_INSTS_VALU_FMA_F64 + ADD_F64 + MUL_F64) x active-lane "
                        "share, over the live duration")
-    elif insts:
-        out["achieved"] = insts * FLOP_PER_ISSUE_SLOT / k_s / 1e12
-        out["work"] = ("executed vector instructions per launch (SQ_INSTS_VALU) x 128 FLOP per wave64 issue slot, over the "
-                       "live duration: the share of the FP32 vector unit's issue slots the kernel fills at 2.4 GHz")
-        out["valu_insts_per_launch"] = insts
+    else:
         fl = 64.0 * (2.0 * cnt.get("SQ_INSTS_VALU_FMA_F32", 0.0) + cnt.get("SQ_INSTS_VALU_ADD_F32", 0.0) +
                      cnt.get("SQ_INSTS_VALU_MUL_F32", 0.0) + cnt.get("SQ_INSTS_VALU_TRANS_F32", 0.0))
         if fl > 0:
-            out["executed_fp32_tflops"] = fl * (lanes if lanes else 1.0) / k_s / 1e12
+            out["achieved"] = fl * (lanes if lanes else 1.0) / k_s / 1e12
+            out["work"] = ("executed f32 FLOP per launch = 64 x (2 x SQ_INSTS_VALU_FMA_F32 + ADD_F32 + MUL_F32 + TRANS_F32) x "
+                           "active-lane share, over the live duration")
+        if insts:
+            # the share of the vector unit's issue slots the kernel fills: what bounds it (compares, selects, moves and
+            # integer work fill most of them)
+            out["valu_insts_per_launch"] = insts
+            out["valu_issue_tflops_equiv"] = insts * FLOP_PER_ISSUE_SLOT / k_s / 1e12
+            out["valu_issue_frac"] = out["valu_issue_tflops_equiv"] / (peak / 1e12)
+            if lanes:
+                out["valu_issue_frac_active_lanes"] = out["valu_issue_frac"] * lanes
     if out["achieved"] is not None:
         out["frac"] = out["achieved"] / (peak / 1e12)
     if lanes:
         out["active_lane_share"] = lanes
-        if out["frac"] is not None and not f64:
-            out["useful_frac"] = out["frac"] * lanes
     if cnt.get("GRBM_GUI_ACTIVE") and cnt.get("kernel_ms_under_counters"):
         out["clock_ghz_under_counters"] = cnt["GRBM_GUI_ACTIVE"] / 8.0 / (cnt["kernel_ms_under_counters"] * 1e-3) / 1e9
     if "FETCH_SIZE" in cnt and "WRITE_SIZE" in cnt:
         # KiB per launch; FETCH_SIZE counts a wide coalesced read at half its bytes on gfx950
         out["traffic"] = 2 * 1024.0 * cnt["FETCH_SIZE"] + 1024.0 * cnt["WRITE_SIZE"]
         out["traffic_unit"] = "HBM bytes per launch: FETCH_SIZE x 2 + WRITE_SIZE, one rocprofv3 --pmc pass each"
-    if not current:
-        out["note"] = "the committed counter pass was taken on other kernel sources than these: counter-derived fields are stale"
     return out
 
 
@@ -357,7 +368,7 @@ def main():
                                "unit": "TFLOP/s", "frac": ref_equiv / PEAK_FP32_VALU, "traffic": None, "kernel": kernel,
                                "kernel_ms": k_s * 1e3,
                                "work": "18 FLOP x spheres x segments of one launch (every test is executed), over the live duration"}
-            if cnt and "FETCH_SIZE" in cnt and "WRITE_SIZE" in cnt and current:
+            if cnt and current and "FETCH_SIZE" in cnt and "WRITE_SIZE" in cnt:
                 out["roofline"]["traffic"] = 2 * 1024.0 * cnt["FETCH_SIZE"] + 1024.0 * cnt["WRITE_SIZE"]
         else:
             out["roofline"] = executed_roofline(cnt, current, cfile, kernel, k_s,

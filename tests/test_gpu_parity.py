@@ -1206,6 +1206,23 @@ def test_rccl_gather_on_one_gpu(dray, gpu):
         image = partition.gather_image(r.color, r.H, None, always_collective=True)
         torch.cuda.synchronize()
         assert (gpu.color_to_numpy(image.contiguous()) == full[0]).all() and st.segments == full[3].segments
+        # Steps enqueued back to back, as bench.py does: the second step's trace kernel is enqueued (on the scene's other
+        # trace stream, where it may start at once) while the first step's gather is still on its way.  The first
+        # gather must hold the first step's picture, the second the picture after both.
+        cam8 = dray.camera_final(width=96, spp=12, depth=20)
+        cam8.mode = dray.MODE_F32
+        after_three = render_gpu(dray, gpu, spheres, cam8, seed=cam.seed)
+        cam.samples_per_pixel = 4
+        _, t2 = r.step(gather=False, stats_later=True)
+        image2 = partition.gather_image(r.color, r.H, None, always_collective=True)
+        _, t3 = r.step(gather=False, stats_later=True)
+        image3 = partition.gather_image(r.color, r.H, None, always_collective=True)
+        torch.cuda.synchronize()
+        cam8.samples_per_pixel = 8
+        after_two = render_gpu(dray, gpu, spheres, cam8, seed=cam.seed)
+        assert (gpu.color_to_numpy(image2.contiguous()) == after_two[0]).all()
+        assert (gpu.color_to_numpy(image3.contiguous()) == after_three[0]).all()
+        assert st.segments + t2.stats().segments + t3.stats().segments == after_three[3].segments
         scene.close()
     finally:
         dist.destroy_process_group()
@@ -1254,10 +1271,15 @@ def test_f64_stream_kernel_shapes_of_work(dray, gpu, oracle):
     one-thread-per-pixel kernel and the oracle, bit for bit, where its bookkeeping is under strain: one sample per
     pixel (a chunk of 256 pixels per grab), more samples per pixel than a chunk holds (one pixel per grab), a frame
     smaller than one chunk, a frame of one pixel column, row partitions (strided and compact), sums continued over
-    two calls, and paths of up to 100 segments whose neighbours finish hundreds of samples before they do (the
-    ring of finished samples fills up behind them)."""
+    two calls, paths of up to 100 segments whose neighbours finish hundreds of samples before they do (the
+    ring of finished samples fills up behind them), and -- on a frame smaller than one chunk and on a larger one --
+    paths that walk through Transparent spheres until their depth of 100 is spent."""
     final, three, glass = dray.scene_final(1), dray.scene_three_spheres(), dray.scene_glass_metal(1)
+    through = final.copy()   # a third of the small spheres and the large glass one hand their ray back (material.rs:22-31):
+    through["kind"][1:len(through) - 3:3] = dray._ffi.MAT_TRANSPARENT   # a path that meets one burns all the depth it has
+    through["kind"][len(through) - 3] = dray._ffi.MAT_TRANSPARENT
     cases = [("1spp", final, dict(width=160, spp=1, depth=50)), ("300spp", final, dict(width=24, spp=300, depth=50)),
+             ("burn", through, dict(width=12, spp=5, depth=100)), ("burn_wide", through, dict(width=64, spp=70, depth=100)),
              ("tiny", three, dict(width=5, spp=3, depth=10)), ("column", final, dict(width=1, spp=40, depth=20)),
              ("deep", glass, dict(width=40, spp=700, depth=100)), ("odd", final, dict(width=97, spp=37, depth=12))]
     for name, spheres, kw in cases:
@@ -1271,7 +1293,7 @@ def test_f64_stream_kernel_shapes_of_work(dray, gpu, oracle):
             assert a[3].segments == b[3].segments and a[3].samples == b[3].samples, (name, flags)
             m = render_gpu_grid_from_memory(dray, gpu, spheres, cam, seed=29)              # the stream without its LDS copy of the grid
             assert (a[0] == m[0]).all() and (a[1] == m[1]).all() and a[3].segments == m[3].segments, (name, flags)
-        if name in ("1spp", "tiny", "column", "odd"):
+        if name in ("1spp", "tiny", "column", "odd", "burn"):
             cam.flags = 0
             ocol, oraw, ocnt, ost = oracle.render(ocam_from(oracle, cam), spheres, seed=29, threads=8)
             a = render_gpu(dray, gpu, spheres, cam, seed=29)
