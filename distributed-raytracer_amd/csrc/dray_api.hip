@@ -216,7 +216,7 @@ void scene_free(dray_scene* s) {
     (void)hipFree(d.narrow_index); (void)hipFree(d.wide_index);
     (void)hipFree(d.grid_cells); (void)hipFree(d.grid_entry_geom); (void)hipFree(d.grid_entry_pos); (void)hipFree(d.grid_loose);
     (void)hipFree(d.box64); (void)hipFree(d.box_index);
-    (void)hipFree(d.loose_geom); (void)hipFree(d.loose_index); (void)hipFree(d.wide_geom64);
+    (void)hipFree(d.loose_geom); (void)hipFree(d.loose_index); (void)hipFree(d.wide_geom64); (void)hipFree(d.wide_axial);
     (void)hipFree(d.entry_geom64); (void)hipFree(d.entry_index); (void)hipFree(d.always_geom64); (void)hipFree(d.always_index);
     (void)hipFree(s->d_counter_block); (void)hipFree(s->d_rings);
     for (TraceSpace& t : s->space) {
@@ -581,7 +581,17 @@ int scene_create_impl(const dray_sphere* sp, size_t n, int32_t device, dray_scen
         std::vector<double> wg(4 * widx.size());
         for (size_t k = 0; k < widx.size(); ++k)
             for (int q = 0; q < 4; ++q) wg[4 * k + q] = g64[4 * (size_t)widx[k] + q];
-        if ((rc = upload(&d.loose_geom, lg)) || (rc = upload(&d.loose_index, li)) || (rc = upload(&d.wide_geom64, wg))) {
+        // the same rows for the f32 kernel's cancellation-free form (F32Tables::wide_axial)
+        std::vector<float> wa(8 * widx.size());
+        for (size_t k = 0; k < widx.size(); ++k) {
+            const double* g = &g64[4 * (size_t)widx[k]];
+            const bool axial = std::isfinite(g[0]) && std::isfinite(g[1]) && std::isfinite(g[2]) && std::isfinite(g[3]) &&
+                               std::fabs(g[0]) <= g[3] / 32. && std::fabs(g[2]) <= g[3] / 32.;
+            wa[8 * k + 0] = (float)g[0]; wa[8 * k + 1] = (float)g[1]; wa[8 * k + 2] = (float)g[2]; wa[8 * k + 3] = (float)(1.0 / g[3]);
+            wa[8 * k + 4] = (float)(g[1] + g[3]); wa[8 * k + 5] = (float)(g[1] - g[3]); wa[8 * k + 6] = axial ? 1.f : 0.f; wa[8 * k + 7] = 0.f;
+        }
+        if ((rc = upload(&d.loose_geom, lg)) || (rc = upload(&d.loose_index, li)) || (rc = upload(&d.wide_geom64, wg)) ||
+            (rc = upload(&d.wide_axial, wa))) {
             scene_free(s);
             return rc;
         }
@@ -620,6 +630,7 @@ int scene_create_impl(const dray_sphere* sp, size_t n, int32_t device, dray_scen
     d.f32.wide_index = d.wide_index;
     d.f32.geom64 = d.geom64;
     d.f32.wide_geom64 = d.wide_geom64;
+    d.f32.wide_axial = (const float4*)d.wide_axial;
     d.grid.entry_index = d.entry_index;
     d.f32.geom32 = (const float4*)d.geom32;
     d.f32.mat32 = (const float4*)d.mat32;

@@ -40,6 +40,10 @@ struct F32Tables {
     const int32_t* wide_index = nullptr;   // positions of the wide spheres, ascending
     const double* geom64 = nullptr;        // n x 4: cx, cy, cz, radius
     const double* wide_geom64 = nullptr;   // n_wide x 4: the wide spheres' rows of geom64, one after the other
+    // n_wide x 2: per wide sphere (cx, cy, cz, 1 / r) and (cy + r, cy - r, axial, 0) in f32.  axial = 1: the centre lies so
+    // close to the y axis that |oc|^2 - r^2 = ocx^2 + ocz^2 + (cy + r - oy)(cy - r - oy) is formed in f32 without
+    // cancellation (the ground of src/main.rs:14); 0: the sphere is intersected in f64
+    const float4* wide_axial = nullptr;
     const float4* geom32 = nullptr;        // n: cx, cy, cz, radius
     const float4* mat32 = nullptr;         // n: albedo rgb, fuzz or refraction index
     const uint32_t* kind = nullptr;        // n: material kind
@@ -100,6 +104,7 @@ struct SceneDev {
     float* loose_geom = nullptr;
     int32_t* loose_index = nullptr;
     double* wide_geom64 = nullptr;
+    float* wide_axial = nullptr;
     size_t grid_entries = 0;
     uint32_t grid_max_cell_entries = 0; // the longest cell list
     GridDev grid{};

@@ -497,6 +497,7 @@ struct F32Args {
     const int32_t* wide_index;
     const double* geom64;
     const double* wide_geom64;
+    const V4* wide_axial;
     const V4* geom32;
     const V4* mat32;
     const uint32_t* kind;
@@ -806,7 +807,37 @@ __device__ __forceinline__ void render_f32_body() {
             const int32_t n_wide = a->n_wide;
             ConstPtr<int32_t> wide_index = as_constant(a->wide_index);
             ConstPtr<double> geom64 = as_constant(a->wide_geom64); // the wide spheres' rows, side by side
+            ConstPtr<V4> wide_axial = as_constant(a->wide_axial);
             for (int32_t wq = 0; wq < n_wide; ++wq) {
+#ifndef DRAY_NO_AXIAL
+                if (wide_axial[2 * wq + 1].z != 0.f) {
+                    // A wide sphere whose centre lies by the y axis (the ground, src/main.rs:14), sphere.rs:28-57 in f32 without
+                    // the cancellation of |oc|^2 - r^2: c = ocx^2 + ocz^2 + (cy + r - oy)(cy - r - oy), the two sums
+                    // rounded once on the host; and of the two roots the one that is a sum comes from h and the square
+                    // root, the other from c divided by it (their product is c): no difference of large numbers anywhere.
+                    const int32_t idx = wide_index[wq];
+                    const V4 g = wide_axial[2 * wq], k = wide_axial[2 * wq + 1];
+                    const float ocx = g.x - ox, ocy = g.y - oy, ocz = g.z - oz;
+                    const float h = fmaf(ocz, dz, fmaf(ocy, dy, ocx * dx));
+                    const float c = fmaf(k.x - oy, k.y - oy, fmaf(ocz, ocz, ocx * ocx));
+                    const float disc = fmaf(h, h, -c);
+                    if (disc >= 0.f) {
+                        const float sq = fsqrt(disc);
+                        const bool up = h >= 0.f;
+                        const float big = up ? h + sq : h - sq;
+                        const float small = c * rcp(big); // (big = 0 only with c = 0: NaN, which fails the comparisons below)
+                        float t = up ? small : big;       // the near root
+                        if (!(t > tmin)) t = up ? big : small;
+                        if (t > tmin && (t < best || (t == best && idx < bidx))) {
+                            best = t;
+                            bidx = idx;
+                            hp = {fmaf(t, dx, ox), fmaf(t, dy, oy), fmaf(t, dz, oz)};
+                            hn = {(hp.x - g.x) * g.w, (hp.y - g.y) * g.w, (hp.z - g.z) * g.w}; // sphere.rs:52
+                        }
+                    }
+                    continue;
+                }
+#endif
                 // sphere.rs:28-57 in f64 for a sphere too large for f32: the cancelling terms (oc, |oc|^2 - r^2,
                 // the discriminant, the hit point relative to the centre) are f64; divisions are avoided
                 // (1/|d|^2 = 2 - |d|^2 to 1e-14 because d is unit to f32 rounding; sqrt = f32 estimate + one Newton step)
@@ -1239,7 +1270,7 @@ hipError_t launch_render_f32(const CamDev<float>& cam, const SceneDev& scene, co
     args.cam = cam;
     args.narrow_geom = (const V4*)t.narrow_geom; args.filter_xy = (const V4*)t.filter_xy; args.filter_zn = (const V4*)t.filter_zn;
     args.narrow_index = t.narrow_index; args.wide_index = t.wide_index;
-    args.geom64 = t.geom64; args.wide_geom64 = t.wide_geom64; args.geom32 = (const V4*)t.geom32; args.mat32 = (const V4*)t.mat32; args.kind = t.kind;
+    args.geom64 = t.geom64; args.wide_geom64 = t.wide_geom64; args.wide_axial = (const V4*)t.wide_axial; args.geom32 = (const V4*)t.geom32; args.mat32 = (const V4*)t.mat32; args.kind = t.kind;
     args.n_narrow_padded = t.n_narrow_padded; args.n_wide = t.n_wide;
     args.box64 = scene.box64; args.box_index = scene.box_index; args.n_boxes = scene.n_boxes;
     for (int q = 0; q < 4; ++q) args.bound[q] = t.bound[q];
