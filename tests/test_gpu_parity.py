@@ -324,8 +324,9 @@ def test_f32_three_spheres_close_to_oracle(dray, gpu, oracle):
     d = lsb_diff(col, ocol)
     report("f32_vs_oracle_three_spheres_200x112_20spp", within_1lsb=float((d.max(-1) <= 1).mean()), max=int(d.max()),
            mean=float(d.mean()))
-    # measured: 99.996 % within 1 LSB, max 2, mean 6e-5
-    assert (d.max(-1) <= 1).mean() >= 0.9999 and d.max() <= 4
+    # measured: 99.991 % within 1 LSB, max 6 (one sample of a pixel's 20 taking another turn), mean 1e-4; 99.996 % and
+    # max 2 while the ground sphere was intersected in f64, more exactly than the narrow spheres are
+    assert (d.max(-1) <= 1).mean() >= 0.9999 and d.max() <= 8
     assert d.mean() < 0.001
 
 
