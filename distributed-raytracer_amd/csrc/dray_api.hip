@@ -1612,6 +1612,12 @@ int path_step_device_impl(dray_scene* scene, int32_t image_width, dray_path_entr
     if (g.err != hipSuccess) return hip_fail(g.err, "hipSetDevice");
     const RngKey key = {(uint32_t)opts.seed, (uint32_t)(opts.seed >> 32), opts.sample_offset};
     hipStream_t stream = (hipStream_t)stream_v;
+    // DRAY_MODE_F32: the step at the throughput kernel's precision (a list with bounding boxes takes the f64 step)
+    const bool f32 = opts.mode == DRAY_MODE_F32 && scene->dev.n_boxes == 0;
+    auto launch = [&](DeviceCounters* counters) {
+        return f32 ? launch_path_step_f32(scene->dev, key, image_width, d_entries, n, counters, stream)
+                   : launch_path_step(scene->dev, key, image_width, opts.variant != DRAY_SCAN_SCALAR, d_entries, n, counters, stream);
+    };
     if (count) { // only the counting form touches the scene's workspace; the plain form reads the sphere tables alone
         std::lock_guard<std::mutex> lock(scene->mu);
         if (scene->last_done && scene->last_stream != stream) HIP_TRY(hipStreamWaitEvent(stream, scene->last_done, 0));
@@ -1622,8 +1628,7 @@ int path_step_device_impl(dray_scene* scene, int32_t image_width, dray_path_entr
         slot->base.n_spheres = scene->dev.n;
         HIP_TRY(hipMemsetAsync(slot->d_counters, 0, sizeof(DeviceCounters), stream));
         HIP_TRY(hipEventRecord(slot->ev[0], stream));
-        HIP_TRY(launch_path_step(scene->dev, key, image_width, opts.variant != DRAY_SCAN_SCALAR, d_entries, n,
-                                 slot->d_counters, stream));
+        HIP_TRY(launch(slot->d_counters));
         HIP_TRY(hipEventRecord(slot->ev[1], stream));
         HIP_TRY(counters_to_host(slot, stream));
         HIP_TRY(hipEventRecord(slot->ev[2], stream));
@@ -1631,7 +1636,7 @@ int path_step_device_impl(dray_scene* scene, int32_t image_width, dray_path_entr
         if (ticket) *ticket = slot->ticket;
         return DRAY_OK;
     }
-    HIP_TRY(launch_path_step(scene->dev, key, image_width, opts.variant != DRAY_SCAN_SCALAR, d_entries, n, nullptr, stream));
+    HIP_TRY(launch(nullptr));
     return DRAY_OK;
 }
 

@@ -168,6 +168,8 @@ hipError_t launch_camera_rays(const CamDev<double>& cam, const RngKey& key, cons
                               dray_path_entry* d_out, hipStream_t stream);
 hipError_t launch_path_step(const SceneDev& scene, const RngKey& key, int32_t image_width, bool use_grid,
                             dray_path_entry* d_entries, size_t n, DeviceCounters* d_counters, hipStream_t stream);
+hipError_t launch_path_step_f32(const SceneDev& scene, const RngKey& key, int32_t image_width, dray_path_entry* d_entries,
+                                size_t n, DeviceCounters* d_counters, hipStream_t stream);
 
 // render_f32.hip
 struct F32Plan {

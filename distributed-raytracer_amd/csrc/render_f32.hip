@@ -1147,6 +1147,202 @@ __global__ __launch_bounds__(256) void resolve_f32_kernel(int32_t W, int32_t spp
     color[out] = pack_argb(s0 / denom, s1 / denom, s2 / denom);
 }
 
+
+// ---- the path step in f32: ray_color_iteration (camera.rs:118-144) for a batch, at the throughput kernel's precision ----
+// One thread per entry.  The entry stays the reference's RayColorEntry in f64 (include/dray.h: dray_path_entry); the
+// segment is intersected and scattered in f32 with the building blocks of the trace kernel above -- the origin's move
+// up to the narrow spheres' ball, the grid walk with the exact test and the ordered key, the winner re-evaluated from
+// the perpendicular remainder, wide spheres in the cancellation-free form or in f64, the materials of material.rs
+// -- and with the same streams (stage k: the k-th scatter's draws), so that a path stepped here lands where the trace
+// kernel's sample lands, to f32 rounding.  Lists with bounding boxes take the f64 step (launch_path_step_f32 refuses them).
+struct StepArgs {
+    const V4* geom32;
+    const V4* mat32;
+    const uint32_t* kind;
+    const int32_t* wide_index;
+    const double* wide_geom64;
+    const V4* wide_axial;
+    int32_t n_wide;
+    float bound[4];
+    GridDev grid;
+    RngKey key;
+    int32_t W;
+    dray_path_entry* entries;
+    unsigned long long n;
+    DeviceCounters* counters;
+};
+
+__global__ __launch_bounds__(256) void path_step_f32_kernel(StepArgs) {
+    ConstPtr<StepArgs> a = (ConstPtr<StepArgs>)__builtin_amdgcn_kernarg_segment_ptr();
+    const unsigned long long k = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long my_segments = 0ull;
+    if (k < a->n && !a->entries[k].finished) {
+        dray_path_entry e = a->entries[k];
+        F3 att = {(float)e.attenuation[0], (float)e.attenuation[1], (float)e.attenuation[2]};
+        F3 c = {0.f, 0.f, 0.f};
+        bool finished = true, hit_or_stop = true;
+        if (e.depth > 0) { // else camera.rs:120-123: black
+            my_segments = 1ull;
+            PathRay ray;
+            ray.o = {(float)e.origin[0], (float)e.origin[1], (float)e.origin[2]};
+            set_dir(ray, F3{(float)e.direction[0], (float)e.direction[1], (float)e.direction[2]});
+            { // the origin moves along the ray up to the ball of the narrow spheres (see the trace kernel)
+                const float bx = a->bound[0] - ray.o.x, by = a->bound[1] - ray.o.y, bz = a->bound[2] - ray.o.z;
+                const float s = fmaxf(fmaf(bz, ray.d.z, fmaf(by, ray.d.y, bx * ray.d.x)) - a->bound[3], 0.f);
+                ray.o = {fmaf(s, ray.d.x, ray.o.x), fmaf(s, ray.d.y, ray.o.y), fmaf(s, ray.d.z, ray.o.z)};
+                ray.tmin -= s;
+            }
+            PathRay nray = ray;
+            nray.tmin = fmaxf(ray.tmin, 0.f);
+            Walk walk = {};
+            const GridRegs none = {0.f, 0.f, 0.f, a->grid.cells, nullptr, nullptr};
+            bool walking = walk_begin(&a->grid, none, nray, walk);
+            const GridRegs gr = {(float)a->grid.n[0], (float)a->grid.n[1], (float)a->grid.n[2], a->grid.cells,
+                                 (const V4*)a->grid.entry_geom, a->grid.entry_index};
+            while (walking) walking = walk_step(gr, nray, walk);
+            // the hit: winner of the walk against the wide spheres (hittable_list.rs:60-74), point and normal
+            const float ox = ray.o.x, oy = ray.o.y, oz = ray.o.z, dx = ray.d.x, dy = ray.d.y, dz = ray.d.z;
+            const float tmin = ray.tmin;
+            float best = __uint_as_float((uint32_t)(walk.best >> 32));
+            int32_t bidx = -1;
+            F3 hp = {0.f, 0.f, 0.f}, hn = {0.f, 0.f, 0.f};
+            if (walk.best != kNoHit) {
+                const uint32_t low = (uint32_t)walk.best;
+                bidx = (int32_t)(low >> 1);
+                const V4 s = a->geom32[bidx];
+                const F3 oc = {s.x - ox, s.y - oy, s.z - oz};
+                const float h = dot(oc, ray.d);
+                const F3 l = {fmaf(-h, dx, oc.x), fmaf(-h, dy, oc.y), fmaf(-h, dz, oc.z)};
+                const float sq = fsqrt(fmaxf(fmaf(s.w, s.w, -dot(l, l)), 0.f));
+                best = (low & 1u) ? h + sq : h - sq;
+                hp = {fmaf(best, dx, ox), fmaf(best, dy, oy), fmaf(best, dz, oz)};
+                const float ir = rcp(s.w);
+                hn = {(hp.x - s.x) * ir, (hp.y - s.y) * ir, (hp.z - s.z) * ir}; // sphere.rs:52
+            }
+            for (int32_t wq = 0; wq < a->n_wide; ++wq) {
+                const int32_t idx = a->wide_index[wq];
+                const V4 g = a->wide_axial[2 * wq], kk = a->wide_axial[2 * wq + 1];
+                float t = -1.f;
+                F3 p = {0.f, 0.f, 0.f};
+                if (kk.z != 0.f) { // by the y axis: f32 without cancellation (see the trace kernel)
+                    const float ocx = g.x - ox, ocy = g.y - oy, ocz = g.z - oz;
+                    const float h = fmaf(ocz, dz, fmaf(ocy, dy, ocx * dx));
+                    const float cc = fmaf(kk.x - oy, kk.y - oy, fmaf(ocz, ocz, ocx * ocx));
+                    const float disc = fmaf(h, h, -cc);
+                    if (disc >= 0.f) {
+                        const float sq = fsqrt(disc);
+                        const bool up = h >= 0.f;
+                        const float big = up ? h + sq : h - sq;
+                        const float small = cc * rcp(big);
+                        t = up ? small : big;
+                        if (!(t > tmin)) t = up ? big : small;
+                        if (!(t > tmin)) t = -INFINITY;
+                        p = {fmaf(t, dx, ox), fmaf(t, dy, oy), fmaf(t, dz, oz)};
+                    } else {
+                        t = -INFINITY;
+                    }
+                } else { // sphere.rs:28-57 in f64 (see the trace kernel)
+                    const double cx = a->wide_geom64[4 * wq + 0], cy = a->wide_geom64[4 * wq + 1], cz = a->wide_geom64[4 * wq + 2];
+                    const double rad = a->wide_geom64[4 * wq + 3];
+                    const double ocx = cx - (double)ox, ocy = cy - (double)oy, ocz = cz - (double)oz;
+                    const double ddx = dx, ddy = dy, ddz = dz;
+                    const double aa = fma(ddz, ddz, fma(ddy, ddy, ddx * ddx));
+                    const double h = fma(ddz, ocz, fma(ddy, ocy, ddx * ocx));
+                    const double cc = fma(ocz, ocz, fma(ocy, ocy, fma(ocx, ocx, -(rad * rad))));
+                    const double disc = fma(h, h, -(aa * cc));
+                    t = -INFINITY;
+                    if (disc >= 0.) {
+                        const float s0f = fsqrt((float)disc);
+                        const double s0 = (double)s0f;
+                        const double sq = s0f > 0.f ? fma(fma(-s0, s0, disc), (double)(0.5f * rcp(s0f)), s0) : 0.;
+                        const double inva = 2.0 - aa;
+                        double td = (h - sq) * inva;
+                        if (!(td > (double)tmin)) td = (h + sq) * inva;
+                        if (td > (double)tmin) {
+                            t = (float)td;
+                            p = {(float)fma(td, ddx, (double)ox), (float)fma(td, ddy, (double)oy), (float)fma(td, ddz, (double)oz)};
+                        }
+                    }
+                }
+                if (t > tmin && (t < best || (t == best && idx < bidx))) {
+                    best = t;
+                    bidx = idx;
+                    hp = p;
+                    hn = {(hp.x - g.x) * g.w, (hp.y - g.y) * g.w, (hp.z - g.z) * g.w}; // sphere.rs:52
+                }
+            }
+            if (bidx < 0) { // camera.rs:140-143
+                const float ta = 0.5f * (dy + 1.0f), tw = 1.0f - ta;
+                c = {att.x * fmaf(ta, 0.5f, tw), att.y * fmaf(ta, 0.7f, tw), att.z * fmaf(ta, 1.0f, tw)};
+                hit_or_stop = false;
+            } else { // material.rs, as in the trace kernel
+                const uint32_t mk = a->kind[bidx];
+                const V4 m = a->mat32[bidx];
+                const Stream st = {a->key.k0, a->key.k1, (uint32_t)e.px.pixel_j * (uint32_t)a->W + (uint32_t)e.px.pixel_i,
+                                   a->key.sample_offset + (uint32_t)e.px.pixel_sample_num, e.stage};
+                const bool front = dot(ray.d, hn) < 0.f; // hittable.rs:16-22
+                const F3 n = front ? hn : F3{-hn.x, -hn.y, -hn.z};
+                F3 nd = {0.f, 0.f, 0.f};
+                bool scattered = false;
+                if (mk == DRAY_MAT_LAMBERTIAN || mk == DRAY_MAT_METAL) {
+                    F3 ruv = {0.f, 0.f, 0.f};
+                    for (uint32_t at = 0;; ++at) { // vec3.rs:76-84
+                        uint32_t w[4];
+                        st.block(at, w);
+                        if (unit_vector_attempt(w, ruv)) break;
+                    }
+                    if (mk == DRAY_MAT_LAMBERTIAN) { // material.rs:46-56
+                        nd = n + ruv;
+                        if (fabsf(nd.x) < 1e-8f && fabsf(nd.y) < 1e-8f && fabsf(nd.z) < 1e-8f) nd = n;
+                        scattered = true;
+                    } else { // material.rs:73-80
+                        const float dn = dot(ray.d, n);
+                        const F3 refl = {fmaf(-2.f * dn, n.x, dx), fmaf(-2.f * dn, n.y, dy), fmaf(-2.f * dn, n.z, dz)};
+                        nd = {fmaf(m.w, ruv.x, refl.x), fmaf(m.w, ruv.y, refl.y), fmaf(m.w, ruv.z, refl.z)};
+                        scattered = dot(nd, n) > 0.f;
+                    }
+                    att = {att.x * m.x, att.y * m.y, att.z * m.z};
+                } else if (mk == DRAY_MAT_DIELECTRIC) { // material.rs:103-122
+                    uint32_t w[4];
+                    st.block(0, w);
+                    const float ri = front ? rcp(m.w) : m.w;
+                    const float cos_theta = fminf(-dot(ray.d, n), 1.0f);
+                    const float sin_theta = fsqrt(fmaxf(fmaf(-cos_theta, cos_theta, 1.0f), 0.f));
+                    bool reflects = ri * sin_theta > 1.0f;
+                    if (!reflects) {
+                        float r0 = (1.f - ri) * rcp(1.f + ri);
+                        r0 = r0 * r0;
+                        const float x = 1.f - cos_theta, x2 = x * x;
+                        reflects = fmaf(1.f - r0, x * x2 * x2, r0) > u01<float>(w[0]);
+                    }
+                    if (reflects) {
+                        nd = {fmaf(2.f * cos_theta, n.x, dx), fmaf(2.f * cos_theta, n.y, dy), fmaf(2.f * cos_theta, n.z, dz)};
+                    } else {
+                        const F3 perp = {ri * fmaf(cos_theta, n.x, dx), ri * fmaf(cos_theta, n.y, dy), ri * fmaf(cos_theta, n.z, dz)};
+                        const float kpar = -fsqrt(fabsf(1.0f - dot(perp, perp)));
+                        nd = {fmaf(kpar, n.x, perp.x), fmaf(kpar, n.y, perp.y), fmaf(kpar, n.z, perp.z)};
+                    }
+                    scattered = true;
+                } // else the absorber (material.rs:13-19; Transparent is rendered as one, as in the trace kernel)
+                if (scattered) { // camera.rs:129-133
+                    e.origin[0] = hp.x; e.origin[1] = hp.y; e.origin[2] = hp.z;
+                    e.direction[0] = nd.x; e.direction[1] = nd.y; e.direction[2] = nd.z;
+                    e.depth -= 1;
+                    e.stage += 1u;
+                    finished = false;
+                } // else camera.rs:135: black
+            }
+        }
+        e.attenuation[0] = att.x; e.attenuation[1] = att.y; e.attenuation[2] = att.z;
+        if (finished) { e.color[0] = c.x; e.color[1] = c.y; e.color[2] = c.z; }
+        e.finished = finished ? 1u : 0u;
+        e.hit_object_or_stop = hit_or_stop ? 1u : 0u;
+        a->entries[k] = e;
+    }
+    for (int off = 32; off > 0; off >>= 1) my_segments += __shfl_down(my_segments, off, 64);
+    if ((threadIdx.x & 63) == 0 && a->counters && my_segments) atomicAdd(&a->counters->segments, my_segments);
+}
+
 } // namespace
 
 template <int SCAN>
@@ -1322,6 +1518,26 @@ hipError_t launch_resolve_f32(const CamDev<float>& cam, const Partition& part, c
     const long long grid = (npix + block - 1) / block;
     hipLaunchKernelGGL(resolve_f32_kernel, dim3((unsigned)grid), dim3(block), 0, stream, cam.W, cam.spp, part, d_accum,
                        d_color, d_raw, d_count);
+    return hipGetLastError();
+}
+
+// The f32 path step (path_step_f32_kernel).  Lists with bounding boxes are not for it: hipErrorNotSupported, and the
+// caller takes the f64 step.
+hipError_t launch_path_step_f32(const SceneDev& scene, const RngKey& key, int32_t image_width, dray_path_entry* d_entries,
+                                size_t n, DeviceCounters* d_counters, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    if (scene.n_boxes > 0) return hipErrorNotSupported;
+    const size_t grid = (n + 255) / 256;
+    if (grid > 0x7fffffffu) return hipErrorInvalidValue;
+    const F32Tables& t = scene.f32;
+    StepArgs args{};
+    args.geom32 = (const V4*)t.geom32; args.mat32 = (const V4*)t.mat32; args.kind = t.kind;
+    args.wide_index = t.wide_index; args.wide_geom64 = t.wide_geom64; args.wide_axial = (const V4*)t.wide_axial;
+    args.n_wide = t.n_wide;
+    for (int q = 0; q < 4; ++q) args.bound[q] = t.bound[q];
+    args.grid = scene.grid;
+    args.key = key; args.W = image_width; args.entries = d_entries; args.n = n; args.counters = d_counters;
+    hipLaunchKernelGGL(path_step_f32_kernel, dim3((unsigned)grid), dim3(256), 0, stream, args);
     return hipGetLastError();
 }
 

@@ -275,6 +275,13 @@ __device__ unsigned long long dray_f64_clocks[32];
 #define F64_CLOCK(slot)
 #define F64_COUNT(slot, v)
 #endif
+// DRAY_MARKS (tools/isa_budget.py --kernel f64): named comments in the instruction stream, so that the instructions of
+// each section of the main loop can be counted.
+#ifdef DRAY_MARKS
+#define F64_MARK(name) asm volatile("; MARK " name)
+#else
+#define F64_MARK(name)
+#endif
 
 // One finished sample in a wave's ring: the colour that joins the pixel's sum (camera.rs:223-225: 0 + sample).
 typedef double D2 __attribute__((ext_vector_type(2)));
@@ -455,6 +462,7 @@ void render_f64_stream_kernel(F64Args) {
 #endif
     for (;;) {
         ka = opaque(ka);
+        F64_MARK("A_walk");
         F64_COUNT(16, 1);                              // turns
         F64_COUNT(17, __popcll(__ballot(has)));        // lanes carrying a sample
         // ---- walk steps, while enough lanes are on their way --------------------------------------------------
@@ -512,6 +520,7 @@ void render_f64_stream_kernel(F64Args) {
         }
 
         F64_CLOCK(0);
+        F64_MARK("B_retire");
         // ---- retire: the ring's finished samples, in the order of the stream, join their pixels (colors.rs:38-43) ----
         // Every sample of the stream below `issued` is either in a lane or finished, so the samples before the oldest
         // one in a lane are all in the ring.  The wave retires them 64 at a time (a look at the ring is a trip to
@@ -575,6 +584,7 @@ void render_f64_stream_kernel(F64Args) {
         }
 
         F64_CLOCK(3);
+        F64_MARK("C_settle_hit");
         // ---- lanes whose search is over, or has stopped with its slots full: the candidates take the reference's test ----
         {
             const bool settle = has && !walking && !camera && !dead && !fallback && depth > 0;
@@ -634,6 +644,7 @@ void render_f64_stream_kernel(F64Args) {
         F64_CLOCK(1);
         F64_COUNT(20, __popcll(__ballot(ready)));      // lanes shading
         F64_CLOCK(2);
+        F64_MARK("D_refill");
         // ---- refill: free lanes take the next samples of the stream (camera.rs:217-224) ------------------------
         {
             bool need = !has;
@@ -681,6 +692,7 @@ void render_f64_stream_kernel(F64Args) {
         if (__ballot(has) == 0ull && retired == issued) break; // nothing in flight, nothing left to take
 
         F64_CLOCK(4);
+        F64_MARK("E_philox_block0");
         // ---- the first uniforms of the next step, and the rejection samplers, by the whole wave -----------------
         const bool draws = scatters || camera;
         const Stream st = {ka->key.k0, ka->key.k1, pw, ka->key.sample_offset + smp, camera ? 0u : (uint32_t)(ka->cam.max_depth - depth + 1)};
@@ -690,8 +702,10 @@ void render_f64_stream_kernel(F64Args) {
                               : (camera && ka->cam.defocus != 0)                                      ? (uint32_t)kDraw64UnitDisk
                                                                                                   : (uint32_t)kDraw64None;
         F64_CLOCK(5);
+        F64_MARK("F_coop_draw");
         const Drawn got = coop_draw64(st, w, draw, lds_req, lane);
         F64_CLOCK(6);
+        F64_MARK("G_scatter_sky_end");
 
         // ---- scatter (material.rs) and sky (camera.rs:279-281) ---------------------------------------------
         // Every operation is the reference's, in the reference's order, lane by lane; what is shared is the code.  A
@@ -823,6 +837,7 @@ void render_f64_stream_kernel(F64Args) {
         }
 
         F64_CLOCK(7);
+        F64_MARK("H_camera_ray");
         // ---- camera ray of a new sample: camera.rs:238-262 --------------------------------------------------
         if (camera) {
             double px = 0., py = 0.;
@@ -837,6 +852,7 @@ void render_f64_stream_kernel(F64Args) {
         }
 
         F64_CLOCK(8);
+        F64_MARK("I_new_ray");
         // ---- a new ray: the wide spheres in f64, the f32 view of the ray, the loose spheres, the first cell ------
         if (fresh) {
             my_segments++;
@@ -933,6 +949,7 @@ void render_f64_stream_kernel(F64Args) {
             }
         }
         F64_CLOCK(9);
+        F64_MARK("Z_loop_edge");
     }
 #ifdef DRAY_F64_CLOCKS
     if (lane == 0)

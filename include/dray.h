@@ -325,7 +325,9 @@ int dray_camera_rays(const dray_camera* cam, const dray_pixel_index* px, size_t 
 /* One ray_color_iteration (camera.rs:118-144) on each of n entries, in place: a path is advanced by one segment
  * and can be resumed by the next call, on this or another GPU, in any batch and order.  Entries whose `finished` is
  * set are left alone.  image_width is the camera's (it enters the stream key).  f64, the reference's operation
- * order.  With stats, segments counts the intersected entries. */
+ * order; with opts->mode = DRAY_MODE_F32 the segment is intersected and scattered at the throughput kernel's
+ * precision instead (the entry stays f64; same streams; a list with bounding boxes takes the f64 step either way).
+ * With stats, segments counts the intersected entries. */
 int dray_path_step(dray_scene* scene, int32_t image_width, dray_path_entry* entries, size_t n, const dray_opts* opts,
                    dray_stats* stats);
 /* The same two calls on device pointers (on the scene's device / opts->device), enqueued on `stream`. */

@@ -54,15 +54,19 @@ def classify(op):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--scan", type=int, default=3)
+    ap.add_argument("--kernel", default="f32", choices=["f32", "f64"],
+                    help="f64: the stream kernel of render_f64.hip (recursive product, grid copy in LDS)")
     ap.add_argument("--out", default="")
     args = ap.parse_args()
-    src = os.path.join(ROOT, "distributed-raytracer_amd", "csrc", "render_f32.hip")
+    unit = "render_f32" if args.kernel == "f32" else "render_f64"
+    src = os.path.join(ROOT, "distributed-raytracer_amd", "csrc", unit + ".hip")
     with tempfile.TemporaryDirectory() as tmp:
-        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-DDRAY_MARKS",
-                        "-save-temps", "-c", src, "-o", os.path.join(tmp, "o.o")], cwd=tmp, check=True,
+        exact = [] if args.kernel == "f32" else ["-ffp-contract=off"]
+        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-DDRAY_MARKS"] + exact +
+                       ["-save-temps", "-c", src, "-o", os.path.join(tmp, "o.o")], cwd=tmp, check=True,
                        stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-        asm = open(os.path.join(tmp, "render_f32-hip-amdgcn-amd-amdhsa-gfx950.s")).read().splitlines()
-    name = "render_f32_kernelILi%dELb0E" % args.scan   # <scan, no bounding boxes>; 4 = the grid scan over its copy in LDS   # <scan, no bounding boxes>
+        asm = open(os.path.join(tmp, unit + "-hip-amdgcn-amd-amdhsa-gfx950.s")).read().splitlines()
+    name = "render_f32_kernelILi%dELb0E" % args.scan if args.kernel == "f32" else "render_f64_stream_kernelILb0ELb1E"   # <scan, no bounding boxes>; 4 = the grid scan over its copy in LDS   # <scan, no bounding boxes>
     start = next(i for i, l in enumerate(asm) if l.startswith("_Z") and name in l.split(":")[0] and ":" in l)
     section, order, table = "0_entry", ["0_entry"], {}
     meta = {}
