@@ -622,6 +622,12 @@ __device__ __forceinline__ void render_f32_body() {
     // left the cache
     auto deposit = [&](float cr, float cg, float cb, uint32_t pixel_word, uint32_t slot) {
         const unsigned long long fr = to_fixed(cr), fg = to_fixed(cg), fb = to_fixed(cb);
+#ifdef DRAY_EXPERIMENT_SPREAD_DEPOSITS
+        // Diagnostic builds only (the image is wrong): every lane adds to a slot of its own, which takes the
+        // same-address conflicts of the deposits out of the LDS counters (profiles/r3/47_lds_bank_conflicts.md).
+        slot = (uint32_t)lane & (uint32_t)(kSlots - 1);
+        pixel_word = __hip_atomic_load(&lds_tag[wv][slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
         if (__hip_atomic_load(&lds_tag[wv][slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == pixel_word) {
             __hip_atomic_fetch_add(&lds_sum[wv][slot][0], fr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             __hip_atomic_fetch_add(&lds_sum[wv][slot][1], fg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
