@@ -1408,6 +1408,10 @@ F32Plan plan_render_f32(const CamDev<float>& cam, const Partition& part, int32_t
     if (plan.scan == DRAY_SCAN_HYBRID && occupancy_of<kScanHybrid>(&occ, plan.block, plan.lds_bytes) != hipSuccess) occ = 0;
     if (plan.lds_grid) occ = plan.lds_occupancy;
     if (occ > 0) per_cu = occ;
+    if (const char* env = std::getenv("DRAY_BLOCKS_PER_CU")) { // tuning runs only: fewer resident workgroups than fit
+        const int v = std::atoi(env);
+        if (v > 0 && v < per_cu) per_cu = v;
+    }
     plan.grid = cus * per_cu;
     const long long npix = (long long)part.n_rows * cam.W;
     const int32_t spp = cam.spp > 0 ? cam.spp : 1;
@@ -1520,7 +1524,10 @@ hipError_t launch_resolve_f32(const CamDev<float>& cam, const Partition& part, c
                               uint32_t* d_color, double* d_raw, int32_t* d_count, hipStream_t stream) {
     const long long npix = (long long)part.n_rows * cam.W;
     if (npix <= 0 || cam.spp <= 0) return hipSuccess;
-    const int block = 256;
+#ifndef DRAY_RESOLVE_BLOCK
+#define DRAY_RESOLVE_BLOCK 256
+#endif
+    const int block = DRAY_RESOLVE_BLOCK;
     const long long grid = (npix + block - 1) / block;
     hipLaunchKernelGGL(resolve_f32_kernel, dim3((unsigned)grid), dim3(block), 0, stream, cam.W, cam.spp, part, d_accum,
                        d_color, d_raw, d_count);
