@@ -414,7 +414,9 @@ void render_f64_stream_kernel(F64Args) {
     __shared__ V4f lds_ray[4][4][64];            // RayConst of every lane: [wave][A slack | B on | o tm_lo | u tm_hi][lane]
     __shared__ double lds_acc[4][4];             // running sum of the pixel the wave is retiring: red, green, blue
     static_assert(sizeof(lds_stage_all[0]) >= 64 * sizeof(uint4), "the draw requests share the retirement's staging");
-    const int lane = (int)(threadIdx.x & 63u), wv = (int)(threadIdx.x >> 6);
+    // (the wave's number in its workgroup is the same in every lane; said so that what is read through it -- the
+    // chunk queue -- and every count of the wave's that depends on that stays in scalar registers)
+    const int lane = (int)(threadIdx.x & 63u), wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     double (*lds_stage)[3] = lds_stage_all[wv];
     uint4* lds_req = (uint4*)&lds_stage_all[wv][0][0];
     const uint32_t W = (uint32_t)ka->cam.W, spp = (uint32_t)ka->cam.spp, npix = (uint32_t)ka->part.n_rows * W;
@@ -534,7 +536,9 @@ void render_f64_stream_kernel(F64Args) {
                 uint32_t oldest = has ? item - retired : waiting; // of the samples still in lanes
 #pragma unroll
                 for (int off = 32; off > 0; off >>= 1) oldest = min(oldest, (uint32_t)__shfl_xor((int)oldest, off, 64));
-                n_ok = (int)min(oldest, 64u);
+                // (every lane holds the minimum now; said so that what depends on it stays wave-uniform for the compiler too:
+                // else the loop's exit, and with it every count the wave keeps, is taken to differ from lane to lane)
+                n_ok = (int)min((uint32_t)__builtin_amdgcn_readfirstlane((int)oldest), 64u);
             }
             if (n_ok == 0) break;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // the lanes' stores to the ring have completed
