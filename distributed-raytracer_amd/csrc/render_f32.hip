@@ -580,7 +580,7 @@ __device__ __forceinline__ void render_f32_body() {
     __shared__ uint32_t lds_tag[4][kSlots];              // the slot's pixel: its Philox pixel word (j * W + i)
     __shared__ uint4 lds_req[4][64];                     // coop_draw: streams handed to server lanes
     static_assert(sizeof(lds_sum) + sizeof(lds_tag) + sizeof(lds_req) <= kF32StaticLds, "static LDS outgrew its budget");
-    const int wv = (int)(threadIdx.x >> 6);
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // (the same in every lane of a wave: said so for the compiler)
     if (lane < kSlots) {
         __hip_atomic_store(&lds_tag[wv][lane], kNoPixel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         lds_sum[wv][lane][0] = lds_sum[wv][lane][1] = lds_sum[wv][lane][2] = 0ull;

@@ -455,7 +455,6 @@ void render_f64_stream_kernel(F64Args) {
     uint32_t iss_p0 = 0u, iss_q = 0u, iss_n = 0u;     // the chunk being handed out: first pixel, next sample, samples
     uint32_t ret_p0 = 0u, ret_dp = 0u, ret_np = 0u, ret_s = 0u; // the chunk being retired: first pixel, pixel, pixels; sample
     size_t ret_out = 0;
-    unsigned long long n_samples = 0ull;
     bool exhausted = false;
 
 #ifdef DRAY_F64_CLOCKS
@@ -584,7 +583,6 @@ void render_f64_stream_kernel(F64Args) {
             }
             if (lane < 3) lds_acc[wv][lane] = acc;
             retired += (uint32_t)n_ok;
-            n_samples += (unsigned long long)n_ok;
         }
 
         F64_CLOCK(3);
@@ -965,7 +963,7 @@ void render_f64_stream_kernel(F64Args) {
     for (int off = 32; off > 0; off >>= 1) my_segments += __shfl_down(my_segments, off, 64);
     if (lane == 0 && ka->counters) {
         atomicAdd(&ka->counters->segments, my_segments);
-        atomicAdd(&ka->counters->samples, n_samples);
+        atomicAdd(&ka->counters->samples, (unsigned long long)retired); // every sample handed out has been retired
     }
 }
 
