@@ -442,7 +442,6 @@ void render_f64_stream_kernel(F64Args) {
     bool camera = false;   // ... whose camera ray is still to be made
     bool walking = false;  // on its way through the grid
     bool paused = false;   // ... and stopped with both candidate slots taken: they are evaluated, then the walk goes on
-    bool dead = false;     // the path was absorbed: the sample ends black at the lane's next turn
     bool fallback = false; // the closest hit of this ray comes from the scan of the whole list
     Walk32 wk = {};
     Cand cd = {INFINITY, INFINITY, kNoCand, kNoCand};
@@ -452,7 +451,7 @@ void render_f64_stream_kernel(F64Args) {
     // wave state (the same in every lane)
     uint32_t issued = 0u, retired = 0u;       // samples of the wave's stream handed out / added to their pixels
     uint32_t grabbed = 0u, begun = 0u;        // chunks taken from the queue / chunks whose retirement has begun
-    uint32_t iss_p0 = 0u, iss_q = 0u, iss_n = 0u;     // the chunk being handed out: first pixel, next sample, samples
+    uint32_t iss_p0 = 0u, iss_q = 0u, iss_left = 0u;  // the chunk being handed out: first pixel, next sample, samples left
     uint32_t ret_p0 = 0u, ret_dp = 0u, ret_np = 0u, ret_s = 0u; // the chunk being retired: first pixel, pixel, pixels; sample
     size_t ret_out = 0;
     bool exhausted = false;
@@ -589,7 +588,7 @@ void render_f64_stream_kernel(F64Args) {
         F64_MARK("C_settle_hit");
         // ---- lanes whose search is over, or has stopped with its slots full: the candidates take the reference's test ----
         {
-            const bool settle = has && !walking && !camera && !dead && !fallback && depth > 0;
+            const bool settle = has && !walking && !camera && !fallback && depth > 0;
             if (__ballot(settle && (cd.i0 != kNoCand || cd.i1 != kNoCand)) != 0ull) {
                 const uint32_t k0 = settle ? cd.i0 : kNoCand, k1 = settle ? cd.i1 : kNoCand;
                 // both rows are asked for before either is used: one trip to memory
@@ -615,7 +614,7 @@ void render_f64_stream_kernel(F64Args) {
         uint32_t mk = 0xFFu;
         const uint32_t end_item = item;
         if (ready) {
-            if (depth <= 0 || dead) { // camera.rs:265-267 / :120-123, or absorbed (camera.rs:276): black
+            if (depth <= 0) { // camera.rs:265-267 / :120-123, or absorbed (camera.rs:276; the scatter left no depth): black
                 ended = true;
             } else {
                 if (fallback) { // the reference's own scan, hittable_list.rs:65-70
@@ -637,10 +636,7 @@ void render_f64_stream_kernel(F64Args) {
                     ended = sky = true; // camera.rs:279-281
                 }
             }
-            if (ended) {
-                dead = false;
-                has = false;
-            }
+            if (ended) has = false;
         }
 
         F64_CLOCK(1);
@@ -652,7 +648,7 @@ void render_f64_stream_kernel(F64Args) {
             bool need = !has;
             unsigned long long want = __ballot(need);
             while (want != 0ull) {
-                if (iss_q == iss_n && !exhausted) { // the next chunk of pixels
+                if (iss_left == 0u && !exhausted) { // the next chunk of pixels
                     if (grabbed - begun == kFifoSlots) break;
                     unsigned long long base = 0ull;
                     if (lane == 0) base = atomicAdd(&ka->counters->next_item, (unsigned long long)ka->chunk_pixels);
@@ -665,12 +661,12 @@ void render_f64_stream_kernel(F64Args) {
                         grabbed++;
                         iss_p0 = lo;
                         iss_q = 0u;
-                        iss_n = min(ka->chunk_pixels, npix - lo) * spp;
+                        iss_left = min(ka->chunk_pixels, npix - lo) * spp;
                     }
                 }
                 if (exhausted) break;
                 const uint32_t room = kF64RingEntries - (issued - retired); // a ring's length ahead of the oldest at most
-                const uint32_t avail = min(iss_n - iss_q, room);
+                const uint32_t avail = min(iss_left, room);
                 const uint32_t wanted = (uint32_t)__popcll(want);
                 const uint32_t take = wanted < avail ? wanted : avail;
                 if (take == 0u) break;
@@ -687,6 +683,7 @@ void render_f64_stream_kernel(F64Args) {
                     need = false;
                 }
                 iss_q += take;
+                iss_left -= take;
                 issued += take;
                 want = __ballot(need);
             }
@@ -805,7 +802,7 @@ void render_f64_stream_kernel(F64Args) {
                     depth -= 1;
                     fresh = depth > 0; // with no depth left the sample ends black at the lane's next turn
                 } else {
-                    dead = true; // camera.rs:276
+                    depth = 0; // camera.rs:276: absorbed, the sample ends black at the lane's next turn
                 }
             }
             // ---- samples that end here: their colour goes to its place in the wave's ring ---------------------------
