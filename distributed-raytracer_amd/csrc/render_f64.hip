@@ -453,7 +453,6 @@ void render_f64_stream_kernel(F64Args) {
     uint32_t grabbed = 0u, begun = 0u;        // chunks taken from the queue / chunks whose retirement has begun
     uint32_t iss_p0 = 0u, iss_q = 0u, iss_left = 0u;  // the chunk being handed out: first pixel, next sample, samples left
     uint32_t ret_p0 = 0u, ret_dp = 0u, ret_np = 0u, ret_s = 0u; // the chunk being retired: first pixel, pixel, pixels; sample
-    size_t ret_out = 0;
     bool exhausted = false;
 
 #ifdef DRAY_F64_CLOCKS
@@ -559,6 +558,7 @@ void render_f64_stream_kernel(F64Args) {
                         begun++;
                     }
                     uint32_t word;
+                    size_t ret_out; // (worked out again when the pixel is complete: two scalar registers the loop does not hold)
                     place_of(ret_p0 + ret_dp, ret_out, word);
                     acc = ka->raw ? ka->raw[3 * ret_out + (size_t)ch] : 0.;
                 }
@@ -569,6 +569,9 @@ void render_f64_stream_kernel(F64Args) {
                 ret_s += (uint32_t)take;
                 if (ret_s == spp) { // the pixel is complete
                     const double a0 = readlane_f64(acc, 0), a1 = readlane_f64(acc, 1), a2 = readlane_f64(acc, 2);
+                    uint32_t word;
+                    size_t ret_out;
+                    place_of(ret_p0 + ret_dp, ret_out, word);
                     if (lane == 0) {
                         const int32_t cnt = (ka->count ? ka->count[ret_out] : 0) + (int32_t)spp; // colors.rs:39
                         const double denom = cnt != 0 ? (double)cnt : 1.;                 // colors.rs:40
