@@ -208,7 +208,8 @@ __device__ __forceinline__ bool filter_test(const Filter32& f, float cx, float c
     const float dhi = disc + e, dlo = disc - e;
     const float sq_hi = __builtin_amdgcn_sqrtf(fmaxf(dhi, 0.f)), sq_lo = __builtin_amdgcn_sqrtf(fmaxf(dlo, 0.f));
     const float eh = fmaf(9.5367431640625e-07f, ocn + f.on + sq_hi, 1e-15f);
-    return slot_update(f.tm_lo, f.tm_hi, (h - sq_hi) - eh, (h - sq_lo) + eh, (h + sq_lo) - eh, (h + sq_hi) + eh, dhi < 0.f, dlo > 0.f, k, c);
+    const float wide = sq_hi + eh, tight = sq_lo - eh; // the brackets' half-widths about h: outer and inner
+    return slot_update(f.tm_lo, f.tm_hi, h - wide, h - tight, h + tight, h + wide, dhi < 0.f, dlo > 0.f, k, c);
 }
 
 // One wide sphere: in f32 its |oc|^2 - r^2 cancels, and a bracket as wide as f32 leaves it could not tell the root 0 of
