@@ -18,7 +18,9 @@
 // of every sphere, the same behind a cheap filter, or a walk through a uniform
 // grid.  "Narrow" spheres are tested in f32; "wide" spheres, whose radius is
 // so large that |oc|^2 - r^2 cancels catastrophically in f32 (the 1000-radius
-// ground of src/main.rs:14), are tested in f64.
+// ground of src/main.rs:14), are tested in f32 in a form that does not cancel
+// when their centre lies by the y axis, as every such ground's does, and in
+// f64 otherwise.
 //
 // What bounds the scan on this chip (tools/ubench_operand.hip, tools/ubench_valu.hip): a VALU operation whose
 // operands are all VGPRs costs ~2.2 cycles of a SIMD, one with an SGPR (or DPP) operand ~3.6 cycles of the

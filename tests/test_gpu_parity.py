@@ -1010,6 +1010,13 @@ def test_bounding_box_as_a_hittable(dray, gpu, oracle):
         gpu.ray_color_iteration(e, scene, cam)
         oracle.ray_color_iteration(oe, spheres, W, seed=14)
         assert e.tobytes() == oe.tobytes(), step
+    # the f32 step is not for lists with boxes: asked for, such a list takes the f64 step all the same
+    e32 = gpu.camera_rays(cam, px)
+    cam.mode = dray.MODE_F32
+    for step in range(14):
+        gpu.ray_color_iteration(e32, scene, cam)
+    assert e32.tobytes() == oe.tobytes()
+    cam.mode = dray.MODE_F64
     scene.close()
     # the three-sphere camera sits at the origin, where a box's plane distances do not depend on the ray at all
     three = np.concatenate([dray.scene_three_spheres(), box(0.3, 0.6, 0.2, 0.9, -1.0, 1.0)])
