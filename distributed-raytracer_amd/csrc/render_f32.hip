@@ -626,7 +626,7 @@ __device__ __forceinline__ void render_f32_body() {
         const unsigned long long fr = to_fixed(cr), fg = to_fixed(cg), fb = to_fixed(cb);
 #ifdef DRAY_EXPERIMENT_SPREAD_DEPOSITS
         // Diagnostic builds only (the image is wrong): every lane adds to a slot of its own, which takes the
-        // same-address conflicts of the deposits out of the LDS counters (profiles/r3/47_lds_bank_conflicts.md).
+        // same-address conflicts of the deposits out of the LDS counters: what is left are the grid copy's.
         slot = (uint32_t)lane & (uint32_t)(kSlots - 1);
         pixel_word = __hip_atomic_load(&lds_tag[wv][slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #endif

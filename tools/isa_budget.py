@@ -6,7 +6,7 @@ takes the gfx950 assembly of one kernel and counts the instructions between cons
 vector ALU (with the slow ones apart: 64-bit integer multiply-adds, f64, transcendentals), scalar ALU, LDS, memory.
 A block the compiler moved away from its section is counted where it lies, so the split is approximate.
 
-    python tools/isa_budget.py [--scan 3] [--out profiles/r2/isa_budget_grid.txt]
+    python tools/isa_budget.py [--scan 3] [--kernel f32|f64] [--out isa_budget.txt]
 """
 import argparse
 import os
