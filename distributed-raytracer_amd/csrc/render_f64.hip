@@ -455,6 +455,7 @@ void render_f64_stream_kernel(F64Args) {
     uint32_t iss_p0 = 0u, iss_q = 0u, iss_left = 0u;  // the chunk being handed out: first pixel, next sample, samples left
     uint32_t ret_p0 = 0u, ret_dp = 0u, ret_np = 0u, ret_s = 0u; // the chunk being retired: first pixel, pixel, pixels; sample
     bool exhausted = false;
+    uint32_t idle_turns = 0u; // turns in a row in which no lane carried a sample (see the loop's exit)
 
 #ifdef DRAY_F64_CLOCKS
     unsigned long long clk[32] = {};
@@ -692,7 +693,16 @@ void render_f64_stream_kernel(F64Args) {
                 want = __ballot(need);
             }
         }
-        if (__ballot(has) == 0ull && retired == issued) break; // nothing in flight, nothing left to take
+        if (__ballot(has) == 0ull) {
+            if (retired == issued) break; // nothing in flight, nothing left to take
+            // No lane carries a sample, yet some are issued and not retired: they are all in the ring, and the retirement
+            // above takes them 64 at a time or, with the queue exhausted, all at once -- a few turns at most.  A wave that
+            // finds itself here turn after turn has lost count: it leaves (the call's sample total then falls short,
+            // which its statistics show) instead of holding the GPU for ever.
+            if (++idle_turns > 4096u) break;
+        } else {
+            idle_turns = 0u;
+        }
 
         F64_CLOCK(4);
         F64_MARK("E_philox_block0");
