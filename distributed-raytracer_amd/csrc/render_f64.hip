@@ -155,7 +155,11 @@ __device__ __forceinline__ Drawn coop_draw64(const Stream& st, const uint32_t (&
 //   |disc - disc*| <= E  = 2^-18 (|oc|^2 + r2) + 2^-19 |o~| |oc| + 2^-26 |o~|^2      (measured bound: 26, 14 and 0 units of 2^-24)
 //   |h - h*|       <= Eh = 2^-20 (|oc| + |o~| + sqrt(disc + E))                       (measured bound: 8 and 4 units of 2^-24)
 // with |o~| enlarged by 2^-9 of the distance the origin was moved, which covers the f64 rounding of the reference's own
-// expressions seen from the unmoved origin (2^-50 of that distance squared in disc, 2^-50 of it in h).  Hence
+// expressions seen from the unmoved origin (2^-50 of that distance squared in disc, 2^-50 of it in h).  The test uses
+// them in a form that needs no |oc| (a square root per sphere): |o~| |oc| <= (|o~|^2 + |oc|^2) / 2 and |oc| <= |o~| + C,
+// C the largest |c~| of the narrow spheres, so that
+//   E  <= (2^-18 + 2^-20) (|oc|^2 + r2) + (2^-20 + 2^-26) |o~|^2,     Eh <= 2^-20 (2 |o~| + C + sqrt(disc + E)),
+// each a multiple of what the sphere contributes plus a term of the ray alone (`e0`, `eh0`).  Hence
 //   near root in [h - sqrt(disc + E) - Eh, h - sqrt(disc - E) + Eh],  far root in [h + sqrt(disc - E) - Eh, h + sqrt(disc + E) + Eh],
 // a sphere with disc + E < 0 or far bound below the lower bound is missed for certain, one with disc - E > 0 and a root
 // bound above the lower bound is hit for certain and caps the search (`ub`); everything in between stays a candidate.
@@ -163,8 +167,14 @@ __device__ __forceinline__ Drawn coop_draw64(const Stream& st, const uint32_t (&
 struct Filter32 {
     float ox, oy, oz, ux, uy, uz;
     float tm_lo, tm_hi; // the reference's lower bound on a root (interval.rs:28-30), a hair below and above
-    float on;           // |o~| + 2^-9 of the move
+    float e0, eh0;      // the ray's own share of E and of Eh (filter_consts)
 };
+// The ray's share of the error bounds, from `on` = |o~| + 2^-9 of the move and the narrow spheres' largest |c~|.
+// (The floors 1e-30 and 1e-15 stand above anything f32 underflow can do to a scene of the sizes the search is used for.)
+__device__ __forceinline__ void filter_consts(Filter32& f, float on, float cmax) {
+    f.e0 = fmaf(9.685754776000977e-07f * on, on, 1e-30f);
+    f.eh0 = fmaf(9.5367431640625e-07f, fmaf(2.f, on, cmax), 1e-15f);
+}
 constexpr uint32_t kNoCand = 0xFFFFFFFFu;
 struct Cand {
     float ub;        // an upper bound on the closest accepted root, from spheres hit for certain
@@ -202,12 +212,10 @@ __device__ __forceinline__ bool filter_test(const Filter32& f, float cx, float c
     const float h = fmaf(ocz, f.uz, fmaf(ocy, f.uy, ocx * f.ux));
     const float oc2 = fmaf(ocz, ocz, fmaf(ocy, ocy, ocx * ocx));
     const float disc = fmaf(h, h, r2 - oc2);
-    const float ocn = __builtin_amdgcn_sqrtf(oc2);
-    // (the floors 1e-30 and 1e-15 stand above anything f32 underflow can do to a scene of the sizes the search is used for)
-    const float e = fmaf(1.9073486328125e-06f * f.on, ocn, fmaf(1.4901161193847656e-08f * f.on, f.on, fmaf(3.814697265625e-06f, oc2 + r2, 1e-30f)));
+    const float e = fmaf(4.76837158203125e-06f, oc2 + r2, f.e0);
     const float dhi = disc + e, dlo = disc - e;
     const float sq_hi = __builtin_amdgcn_sqrtf(fmaxf(dhi, 0.f)), sq_lo = __builtin_amdgcn_sqrtf(fmaxf(dlo, 0.f));
-    const float eh = fmaf(9.5367431640625e-07f, ocn + f.on + sq_hi, 1e-15f);
+    const float eh = fmaf(9.5367431640625e-07f, sq_hi, f.eh0);
     const float wide = sq_hi + eh, tight = sq_lo - eh; // the brackets' half-widths about h: outer and inner
     return slot_update(f.tm_lo, f.tm_hi, h - wide, h - tight, h + tight, h + wide, dhi < 0.f, dlo > 0.f, k, c);
 }
@@ -325,6 +333,7 @@ struct F64Args {
     int32_t n_narrow_padded;
     int32_t filter_ok;   // the scene's size is one f32 arithmetic has room for
     double ball[4];
+    float narrow_cmax;   // no finite narrow sphere's centre lies farther from the origin of coordinates than this
     double ball_far2;    // an origin farther than this (squared) from the ball's centre after the move: the ray passes the ball by
     double reach;        // largest origin coordinate the move is made for (beyond: the scan of the whole list)
 };
@@ -343,6 +352,9 @@ __device__ __forceinline__ const DRAY_CONSTANT T* opaque(const DRAY_CONSTANT T* 
     asm volatile("" : "+s"(v));
     return (const DRAY_CONSTANT T*)v;
 }
+
+// A wave-uniform value kept in a scalar register from here on: what produced it cannot be moved below this point.
+template <typename T> __device__ __forceinline__ void held(T& v) { asm volatile("" : "+s"(v)); }
 
 // sphere.rs:28-48 for one sphere against the closest hit so far (smallest root, on equal roots the earlier entry),
 // with the two possible divisions by |d|^2 made from one refined reciprocal where the operands allow (div_by).
@@ -472,7 +484,16 @@ void render_f64_stream_kernel(F64Args) {
             const float gn0 = (float)ka->rg.grid.n[0], gn1 = (float)ka->rg.grid.n[1], gn2 = (float)ka->rg.grid.n[2];
             const V4f q0 = lds_ray[wv][0][lane], q1 = lds_ray[wv][1][lane], q2 = lds_ray[wv][2][lane], q3 = lds_ray[wv][3][lane];
             const float wA[3] = {q0.x, q0.y, q0.z}, wB[3] = {q1.x, q1.y, q1.z}, wslack = q0.w;
-            const Filter32 flt = {q2.x, q2.y, q2.z, q3.x, q3.y, q3.z, q2.w, q3.w, q1.w};
+            Filter32 flt = {q2.x, q2.y, q2.z, q3.x, q3.y, q3.z, q2.w, q3.w, 0.f, 0.f};
+            filter_consts(flt, q1.w, ka->narrow_cmax);
+            // where the cell words and the entries lie in the LDS copy: worked out once a turn and kept in scalar
+            // registers (left to the compiler they are read from the argument block, and waited for, at every step)
+            uint32_t cells_off = (uint32_t)ka->n * (uint32_t)sizeof(V4f);
+            uint32_t entries_off = cells_off + (uint32_t)ka->n_cells * 4u;
+            held(cells_off);
+            held(entries_off);
+            const uint32_t* wcells = (const uint32_t*)((const char*)lds_rows + cells_off);
+            const uint16_t* wentries = (const uint16_t*)((const char*)lds_rows + entries_off);
             do { // at least one step a turn: fewer lanes than a quorum may be all the wave has
                 F64_COUNT(18, 1);                              // walk steps
                 F64_COUNT(19, __popcll(__ballot(walking)));    // lanes walking at them
@@ -494,7 +515,14 @@ void render_f64_stream_kernel(F64Args) {
                         const bool go = inside & !stop;
                         walking = go;
                         const uint32_t ci = (uint32_t)fmaf(fmaf(wk.c[2], gn1, wk.c[1]), gn0, wk.c[0]);
-                        const uint2 cellrec = cell_of(go ? ci : 0u, sphere);
+                        uint2 cellrec;
+                        if constexpr (LDSGRID) {
+                            const uint32_t rec = wcells[go ? ci : 0u];
+                            sphere = rec >> (kLds64BeginBits + kLds64CountBits);
+                            cellrec = make_uint2(rec & ((1u << kLds64BeginBits) - 1u), (rec >> kLds64BeginBits) & ((1u << kLds64CountBits) - 1u));
+                        } else {
+                            cellrec = cell_of(go ? ci : 0u, sphere);
+                        }
                         wk.e = cellrec.x;
                         wk.e_end = go ? cellrec.x + cellrec.y : cellrec.x;
                         entered = true;
@@ -503,7 +531,7 @@ void render_f64_stream_kernel(F64Args) {
                         V4f row;
                         if constexpr (LDSGRID) {
                             if (!entered) // (beside the other lanes' cell read: the two do not depend on one another)
-                                sphere = ((const uint16_t*)((const uint32_t*)(lds_rows + ka->n) + ka->n_cells))[wk.e];
+                                sphere = wentries[wk.e];
                             row = lds_rows[sphere];
                         } else {
                             row = ((const V4f*)ka->rg.grid.entry_geom)[wk.e];
@@ -595,6 +623,10 @@ void render_f64_stream_kernel(F64Args) {
         {
             const bool settle = has && !walking && !camera && !fallback && depth > 0;
             if (__ballot(settle && (cd.i0 != kNoCand || cd.i1 != kNoCand)) != 0ull) {
+                F64_COUNT(21, 1);                                                  // turns that settle candidates
+                F64_COUNT(22, __popcll(__ballot(settle && cd.i0 != kNoCand)));     // first slots evaluated
+                F64_COUNT(23, __ballot(settle && cd.i1 != kNoCand) != 0ull);       // turns with a second slot in some lane
+                F64_COUNT(24, __popcll(__ballot(settle && cd.i1 != kNoCand)));     // second slots evaluated
                 const uint32_t k0 = settle ? cd.i0 : kNoCand, k1 = settle ? cd.i1 : kNoCand;
                 // both rows are asked for before either is used: one trip to memory
                 const double* g0 = ka->geom + 4 * (size_t)(k0 != kNoCand ? k0 : 0u);
@@ -646,7 +678,6 @@ void render_f64_stream_kernel(F64Args) {
 
         F64_CLOCK(1);
         F64_COUNT(20, __popcll(__ballot(ready)));      // lanes shading
-        F64_CLOCK(2);
         F64_MARK("D_refill");
         // ---- refill: free lanes take the next samples of the stream (camera.rs:217-224) ------------------------
         {
@@ -820,6 +851,7 @@ void render_f64_stream_kernel(F64Args) {
                 }
             }
             // ---- samples that end here: their colour goes to its place in the wave's ring ---------------------------
+            F64_CLOCK(7);
             if (ended) {
                 V3<double> c = {0., 0., 0.};
                 if (sky) {
@@ -849,7 +881,7 @@ void render_f64_stream_kernel(F64Args) {
             }
         }
 
-        F64_CLOCK(7);
+        F64_CLOCK(2);
         F64_MARK("H_camera_ray");
         // ---- camera ray of a new sample: camera.rs:238-262 --------------------------------------------------
         if (camera) {
@@ -902,7 +934,8 @@ void render_f64_stream_kernel(F64Args) {
                 const float tm = (float)__builtin_fma(0.001, len, -s0);
                 flt.tm_lo = fmaf(-4.76837158203125e-07f, fabsf(tm), tm);
                 flt.tm_hi = fmaf(4.76837158203125e-07f, fabsf(tm), tm);
-                flt.on = fmaf(0.001953125f, (float)s0, __builtin_amdgcn_sqrtf(fmaf(flt.oz, flt.oz, fmaf(flt.oy, flt.oy, flt.ox * flt.ox))) * 1.000001f);
+                const float on = fmaf(0.001953125f, (float)s0, __builtin_amdgcn_sqrtf(fmaf(flt.oz, flt.oz, fmaf(flt.oy, flt.oy, flt.ox * flt.ox))) * 1.000001f);
+                filter_consts(flt, on, ka->narrow_cmax);
                 { // the spheres every ray meets, rows and list positions through scalar loads: the wide ones (their
                   // |oc|^2 - r^2 cancels in f32: bracketed from f64 values), then the loose ones (narrow spheres kept out of the grid)
                     bool over = false;
@@ -910,7 +943,7 @@ void render_f64_stream_kernel(F64Args) {
                     const DRAY_CONSTANT int32_t* ai = as_constant(ka->rg.always_index);
                     const int32_t n_wide = ka->rg.n_wide;
                     for (int32_t q = 0; q < n_wide; ++q)
-                        over = over | wide_test(flt.tm_lo, flt.tm_hi, flt.on, ro, u, s0, ag[4 * q], ag[4 * q + 1], ag[4 * q + 2], ag[4 * q + 3],
+                        over = over | wide_test(flt.tm_lo, flt.tm_hi, on, ro, u, s0, ag[4 * q], ag[4 * q + 1], ag[4 * q + 2], ag[4 * q + 3],
                                                 (uint32_t)ai[q], cd);
                     const DRAY_CONSTANT V4f* lg = as_constant((const V4f*)ka->rg.grid.loose_geom);
                     const DRAY_CONSTANT int32_t* li = as_constant(ka->rg.grid.loose_index);
@@ -954,7 +987,7 @@ void render_f64_stream_kernel(F64Args) {
                         wk.e_end = cellrec.x + cellrec.y;
                         walking = true;
                         lds_ray[wv][0][lane] = V4f{rc.A[0], rc.A[1], rc.A[2], rc.slack};
-                        lds_ray[wv][1][lane] = V4f{rc.B[0], rc.B[1], rc.B[2], flt.on};
+                        lds_ray[wv][1][lane] = V4f{rc.B[0], rc.B[1], rc.B[2], on};
                         lds_ray[wv][2][lane] = V4f{flt.ox, flt.oy, flt.oz, flt.tm_lo};
                         lds_ray[wv][3][lane] = V4f{flt.ux, flt.uy, flt.uz, flt.tm_hi};
                     }
@@ -1054,6 +1087,7 @@ hipError_t launch_render_f64_stream(const CamDev<double>& cam, const SceneDev& s
             size = std::fmax(size, std::fabs(args.ball[q]));
         }
         args.ball[3] = radius;
+        args.narrow_cmax = (float)((std::sqrt(args.ball[0] * args.ball[0] + args.ball[1] * args.ball[1] + args.ball[2] * args.ball[2]) + radius) * 1.000001);
         size += radius;
         args.ball_far2 = 2.1 * radius * radius;
         // an origin up to 2^20 scene sizes away is moved up to the ball with an error far inside the search's brackets

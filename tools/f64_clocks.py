@@ -14,7 +14,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 SECTIONS = ["walk", "hit", "end_sample", "retire", "refill", "philox_block0", "coop_draw", "scatter", "camera_ray", "new_ray"]
-COUNTS = {16: "turns", 17: "lanes_with_sample", 18: "walk_steps", 19: "walking_lanes_at_steps", 20: "lanes_shading"}
+COUNTS = {16: "turns", 17: "lanes_with_sample", 18: "walk_steps", 19: "walking_lanes_at_steps", 20: "lanes_shading", 21: "settle_turns", 22: "first_slots",
+          23: "settle_turns_with_second_slot", 24: "second_slots"}
 
 
 def main():
