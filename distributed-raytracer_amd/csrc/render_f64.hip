@@ -178,27 +178,29 @@ __device__ __forceinline__ void filter_consts(Filter32& f, float on, float cmax)
 constexpr uint32_t kNoCand = 0xFFFFFFFFu;
 struct Cand {
     float ub;        // an upper bound on the closest accepted root, from spheres hit for certain
-    float lo0;       // a lower bound on the root of the sphere in the first slot
+    float lo0;       // a lower bound on the root of the sphere in the first slot (NaN: the slot is free)
     uint32_t i0, i1; // list positions of the spheres that may hold the closest root (kNoCand: free slot)
 };
 
 // A sphere's root brackets against the search so far: the near root lies in [near_lo, near_hi], the far root in
-// [far_lo, far_hi]; `never` -- no root for certain --, `real` -- two roots for certain.  A sphere that is hit for certain
-// lowers `ub`; the sphere in the first slot leaves it once its lower bound lies beyond `ub` -- its root is then farther
-// than another sphere's --, so that a ray nearly always ends its search with one sphere to take the reference's test, and
-// the second slot is for roots the brackets cannot tell apart.  Returns true when the sphere is a candidate and both
-// slots are taken: the caller has the slots evaluated and tests the sphere again.
+// [far_lo, far_hi].  What is not known is NaN, which fails every comparison: far_hi NaN -- no root for certain (also a
+// sphere that is not finite, which sphere.rs:33-36 never hits: its discriminant is NaN or negative) --, near_hi and
+// far_lo NaN -- not known to have two roots.  A sphere that is hit for certain lowers `ub`; the sphere in the first slot
+// leaves it once its lower bound lies beyond `ub` -- its root is then farther than another sphere's --, so that a ray
+// nearly always ends its search with one sphere to take the reference's test, and the second slot is for roots the
+// brackets cannot tell apart.  (Compares and selects cost a SIMD almost twice what an addition does: the nine and six
+// here are what is left of fourteen and seven.)  Returns true when the sphere is a candidate and both slots are taken:
+// the caller has the slots evaluated and tests the sphere again.
 __device__ __forceinline__ bool slot_update(float tm_lo, float tm_hi, float near_lo, float near_hi, float far_lo, float far_hi,
-                                            bool never, bool real, uint32_t k, Cand& c) {
-    const bool miss = never | (far_hi < tm_lo);
+                                            uint32_t k, Cand& c) {
+    const bool hit = far_hi >= tm_lo;
     const float lo = near_hi < tm_lo ? far_lo : near_lo;
-    const bool sure_near = near_lo > tm_hi;
-    const bool certain = real & (sure_near | (far_lo > tm_hi));
-    const float hi = sure_near ? near_hi : far_hi;
+    const bool certain = far_lo > tm_hi; // two roots, and the far one is accepted if the near one is not
+    const float hi = near_lo > tm_hi ? near_hi : far_hi;
+    c.ub = fminf(c.ub, certain ? hi : INFINITY);
     // a sphere met again (it is listed in several cells) is not taken twice
-    const bool keep = !miss & !(lo > c.ub) & (k != c.i0) & (k != c.i1);
-    c.ub = (certain & keep & (hi < c.ub)) ? hi : c.ub;
-    const bool take0 = keep & ((c.i0 == kNoCand) | (c.lo0 > c.ub)); // a free slot, or one whose sphere has just fallen behind
+    const bool keep = hit & !(lo > c.ub) & (k != c.i0) & (k != c.i1);
+    const bool take0 = keep & !(c.lo0 <= c.ub); // a free slot (lo0 NaN), or one whose sphere has just fallen behind
     const bool free1 = c.i1 == kNoCand;
     c.i1 = (keep & !take0 & free1) ? k : c.i1;
     c.i0 = take0 ? k : c.i0;
@@ -214,10 +216,10 @@ __device__ __forceinline__ bool filter_test(const Filter32& f, float cx, float c
     const float disc = fmaf(h, h, r2 - oc2);
     const float e = fmaf(4.76837158203125e-06f, oc2 + r2, f.e0);
     const float dhi = disc + e, dlo = disc - e;
-    const float sq_hi = __builtin_amdgcn_sqrtf(fmaxf(dhi, 0.f)), sq_lo = __builtin_amdgcn_sqrtf(fmaxf(dlo, 0.f));
+    const float sq_hi = __builtin_amdgcn_sqrtf(dhi), sq_lo = __builtin_amdgcn_sqrtf(dlo); // NaN: no root for certain, not two for certain
     const float eh = fmaf(9.5367431640625e-07f, sq_hi, f.eh0);
     const float wide = sq_hi + eh, tight = sq_lo - eh; // the brackets' half-widths about h: outer and inner
-    return slot_update(f.tm_lo, f.tm_hi, h - wide, h - tight, h + tight, h + wide, dhi < 0.f, dlo > 0.f, k, c);
+    return slot_update(f.tm_lo, f.tm_hi, h - wide, h - tight, h + tight, h + wide, k, c);
 }
 
 // One wide sphere: in f32 its |oc|^2 - r^2 cancels, and a bracket as wide as f32 leaves it could not tell the root 0 of
@@ -249,7 +251,8 @@ __device__ __forceinline__ bool wide_test(float tm_lo, float tm_hi, float on, V3
     const float eps = fmaf(9.5367431640625e-07f, on, fmaf(1.4551915228366852e-11f, size + sqf, dsq));
     const float en = fmaf(1.1920928955078125e-07f, fabsf(near), eps), ef = fmaf(1.1920928955078125e-07f, fabsf(far), eps);
     const float disc_f = (float)disc;
-    return slot_update(tm_lo, tm_hi, near - en, near + en, far - ef, far + ef, disc_f < -e, disc_f > e * 1.0001f + fabsf(disc_f) * 1.1920928955078125e-07f, k, c);
+    const bool never = disc_f < -e, real = disc_f > e * 1.0001f + fabsf(disc_f) * 1.1920928955078125e-07f;
+    return slot_update(tm_lo, tm_hi, near - en, real ? near + en : NAN, real ? far - ef : NAN, never ? NAN : far + ef, k, c);
 }
 
 // A lane's walk through the grid (3-D DDA along the f32 ray), kept across turns of the main loop.  Boundary times are
@@ -457,7 +460,7 @@ void render_f64_stream_kernel(F64Args) {
     bool paused = false;   // ... and stopped with both candidate slots taken: they are evaluated, then the walk goes on
     bool fallback = false; // the closest hit of this ray comes from the scan of the whole list
     Walk32 wk = {};
-    Cand cd = {INFINITY, INFINITY, kNoCand, kNoCand};
+    Cand cd = {INFINITY, NAN, kNoCand, kNoCand};
     double closest = INFINITY; // smallest root the reference's test has accepted so far, and its sphere's list position
     int32_t best = 0x7fffffff;
 
@@ -634,7 +637,7 @@ void render_f64_stream_kernel(F64Args) {
                 const D2 g0a = *(const D2*)g0, g0b = *(const D2*)(g0 + 2), g1a = *(const D2*)g1, g1b = *(const D2*)(g1 + 2);
                 if (k0 != kNoCand) exact_test(V3<double>{g0a.x, g0a.y, g0b.x}, g0b.y, (int32_t)k0, ro, rd, closest, best);
                 if (k1 != kNoCand) exact_test(V3<double>{g1a.x, g1a.y, g1b.x}, g1b.y, (int32_t)k1, ro, rd, closest, best);
-                if (settle) cd.i0 = cd.i1 = kNoCand;
+                if (settle) { cd.i0 = cd.i1 = kNoCand; cd.lo0 = NAN; }
             }
             if (paused) { // the sphere the walk stopped at is tested again at the next step, with the slots free
                 walking = true;
@@ -903,7 +906,7 @@ void render_f64_stream_kernel(F64Args) {
             my_segments++;
             closest = INFINITY;
             best = 0x7fffffff;
-            cd = {INFINITY, INFINITY, kNoCand, kNoCand};
+            cd = {INFINITY, NAN, kNoCand, kNoCand};
             wk.e = wk.e_end = 0u;
             walking = false;
             paused = false;
