@@ -336,11 +336,11 @@ __device__ __forceinline__ void walk_test(Walk& w, const V4 s, int32_t pos, cons
     const float h = fmaf(ocz, ray.d.z, fmaf(ocy, ray.d.y, ocx * ray.d.x));
     const float q = fmaf(-ocz, ocz, fmaf(-ocy, ocy, fmaf(-ocx, ocx, s.w)));
     const float disc = fmaf(h, h, q);
-    const float sq = fsqrt(fmaxf(disc, 0.f));
+    const float sq = fsqrt(disc); // NaN for a negative discriminant: then t is NaN and fails the comparison below
     const float t0 = h - sq;
     const bool far = !(t0 > ray.tmin);
     const float t = far ? h + sq : t0;
-    const bool valid = (disc >= 0.f) & (t > ray.tmin); // t > tmin > 0: its bits order like an unsigned integer
+    const bool valid = t > ray.tmin; // t > tmin > 0: its bits order like an unsigned integer
     const unsigned long long key =
         ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)(((uint32_t)pos << 1) | (far ? 1u : 0u));
     w.best = (valid & (key < w.best)) ? key : w.best;
@@ -365,19 +365,17 @@ __device__ __forceinline__ bool walk_begin(ConstPtr<GridDev> gp, const Grid& vie
     float t_in = 0.f, t_out = INFINITY, bmax = 0.f;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-        if (fabsf(d[a]) > 1e-12f) {
-            const float inv = rcp(d[a]);
-            w.A[a] = g.cell[a] * inv;
-            const float t0 = (g.lo[a] - o[a]) * inv, t1 = (g.hi[a] - o[a]) * inv;
-            w.B[a] = d[a] >= 0.f ? t0 + w.A[a] : t0; // leaving cell k towards larger indices happens at plane k + 1
-            t_in = fmaxf(t_in, fminf(t0, t1));
-            t_out = fminf(t_out, fmaxf(t0, t1));
-            bmax = fmaxf(bmax, fmaxf(fabsf(t0), fabsf(w.B[a])));
-        } else { // parallel to the axis' planes: never crosses one; misses the grid if outside its slab
-            w.A[a] = 0.f;
-            w.B[a] = INFINITY;
-            if (o[a] < g.lo[a] || o[a] > g.hi[a]) t_out = -INFINITY;
-        }
+        // A direction parallel to the axis' planes (or NaN) walks as one that crosses them after 10^12 cell sizes: from
+        // inside the slab every plane is ~10^12 away and never the next one, from outside t_in > t_out.  (No compares
+        // or selects: each costs a SIMD almost twice an addition, and the set-up had nine per axis.)
+        const float da = copysignf(fmaxf(fabsf(d[a]), 1e-12f), d[a]);
+        const float inv = rcp(da);
+        w.A[a] = g.cell[a] * inv;
+        const float t0 = (g.lo[a] - o[a]) * inv, t1 = (g.hi[a] - o[a]) * inv;
+        w.B[a] = t0 + fmaxf(w.A[a], 0.f); // leaving cell k towards larger indices happens at plane k + 1
+        t_in = fmaxf(t_in, fminf(t0, t1));
+        t_out = fminf(t_out, fmaxf(t0, t1));
+        bmax = fmaxf(bmax, fmaxf(fabsf(t0), fabsf(w.B[a])));
     }
     w.slack = bmax * 3.814697265625e-6f; // 2^-18 of the largest term the boundary times are formed from
     const bool walking = t_in <= t_out + w.slack;
@@ -435,8 +433,8 @@ __device__ __forceinline__ bool walk_step(const GridRegs& g, const PathRay& ray,
         const float tz = fmaf(w.c[2], w.A[2], w.B[2]);
         const float t_exit = fminf(tx, fminf(ty, tz));
         const bool stop = __uint_as_float((uint32_t)(w.best >> 32)) < fmaf(t_exit, 1.f - 3.814697265625e-6f, -w.slack);
-        const bool sx = (tx <= ty) & (tx <= tz);
-        const bool sy = !sx & (ty <= tz);
+        const bool sx = tx == t_exit;
+        const bool sy = !sx & (ty == t_exit);
         // one step along the axis left first; A carries the direction's sign (a parallel axis is never chosen)
         w.c[0] += sx ? copysignf(1.f, w.A[0]) : 0.f;
         w.c[1] += sy ? copysignf(1.f, w.A[1]) : 0.f;
@@ -466,8 +464,8 @@ __device__ __forceinline__ bool walk_step(const GridLds& g, const PathRay& ray, 
         const float tz = fmaf(w.c[2], w.A[2], w.B[2]);
         const float t_exit = fminf(tx, fminf(ty, tz));
         const bool stop = __uint_as_float((uint32_t)(w.best >> 32)) < fmaf(t_exit, 1.f - 3.814697265625e-6f, -w.slack);
-        const bool sx = (tx <= ty) & (tx <= tz);
-        const bool sy = !sx & (ty <= tz);
+        const bool sx = tx == t_exit;
+        const bool sy = !sx & (ty == t_exit);
         w.c[0] += sx ? copysignf(1.f, w.A[0]) : 0.f;
         w.c[1] += sy ? copysignf(1.f, w.A[1]) : 0.f;
         w.c[2] += (sx | sy) ? 0.f : copysignf(1.f, w.A[2]);
