@@ -507,8 +507,8 @@ void render_f64_stream_kernel(F64Args) {
                         const float tx = fmaf(wk.c[0], wA[0], wB[0]), ty = fmaf(wk.c[1], wA[1], wB[1]), tz = fmaf(wk.c[2], wA[2], wB[2]);
                         const float t_exit = fminf(tx, fminf(ty, tz));
                         const bool stop = cd.ub < fmaf(t_exit, 1.f - 3.814697265625e-6f, -wslack); // nothing beyond this cell can be closer
-                        const bool sx = (tx <= ty) & (tx <= tz);
-                        const bool sy = !sx & (ty <= tz);
+                        const bool sx = tx == t_exit;
+                        const bool sy = !sx & (ty == t_exit);
                         // one step along the axis left first; A carries the direction's sign (a parallel axis is never chosen)
                         wk.c[0] += sx ? copysignf(1.f, wA[0]) : 0.f;
                         wk.c[1] += sy ? copysignf(1.f, wA[1]) : 0.f;
@@ -962,19 +962,17 @@ void render_f64_stream_kernel(F64Args) {
                     float t_in = 0.f, t_out = INFINITY, bmax = 0.f;
 #pragma unroll
                     for (int ax = 0; ax < 3; ++ax) {
-                        if (fabsf(d[ax]) > 1e-12f) {
-                            const float inv = __builtin_amdgcn_rcpf(d[ax]);
-                            rc.A[ax] = ka->rg.grid.cell[ax] * inv;
-                            const float t0 = (ka->rg.grid.lo[ax] - o[ax]) * inv, t1 = (ka->rg.grid.hi[ax] - o[ax]) * inv;
-                            rc.B[ax] = d[ax] >= 0.f ? t0 + rc.A[ax] : t0; // leaving cell k towards larger indices happens at plane k + 1
-                            t_in = fmaxf(t_in, fminf(t0, t1));
-                            t_out = fminf(t_out, fmaxf(t0, t1));
-                            bmax = fmaxf(bmax, fmaxf(fabsf(t0), fabsf(rc.B[ax])));
-                        } else { // parallel to the axis' planes: never crosses one; misses the grid if outside its slab
-                            rc.A[ax] = 0.f;
-                            rc.B[ax] = INFINITY;
-                            if (o[ax] < ka->rg.grid.lo[ax] || o[ax] > ka->rg.grid.hi[ax]) t_out = -INFINITY;
-                        }
+                        // A direction parallel to the axis' planes walks as one that crosses them after 10^12 cell sizes:
+                        // from inside the slab every plane is ~10^12 away and never the next one, from outside
+                        // t_in > t_out.  (No compares, selects or branches in the set-up of an axis.)
+                        const float da = copysignf(fmaxf(fabsf(d[ax]), 1e-12f), d[ax]);
+                        const float inv = __builtin_amdgcn_rcpf(da);
+                        rc.A[ax] = ka->rg.grid.cell[ax] * inv;
+                        const float t0 = (ka->rg.grid.lo[ax] - o[ax]) * inv, t1 = (ka->rg.grid.hi[ax] - o[ax]) * inv;
+                        rc.B[ax] = t0 + fmaxf(rc.A[ax], 0.f); // leaving cell k towards larger indices happens at plane k + 1
+                        t_in = fmaxf(t_in, fminf(t0, t1));
+                        t_out = fminf(t_out, fmaxf(t0, t1));
+                        bmax = fmaxf(bmax, fmaxf(fabsf(t0), fabsf(rc.B[ax])));
                     }
                     rc.slack = bmax * 3.814697265625e-6f; // 2^-18 of the largest term the boundary times are formed from
                     if (t_in <= t_out + rc.slack && !(cd.ub < t_in - rc.slack)) {
