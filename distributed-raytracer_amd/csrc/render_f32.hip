@@ -226,7 +226,6 @@ __device__ __forceinline__ uint32_t to_fixed(float c) {
 struct ScanBest {
     float t;     // closest accepted root so far (INFINITY: none)
     int32_t pos; // its position in the narrow table, -1: none
-    bool far;    // the far root was the accepted one
 };
 
 // The exact f32 test of one narrow sphere, sphere.rs:29-48 with |d| = 1: disc = h^2 - (|oc|^2 - r^2).
@@ -245,7 +244,6 @@ __device__ __forceinline__ void exact_test(ScanBest& b, const V s, const PathRay
         if (t > ray.tmin && t < b.t) { // interval.rs:28-30; strict: on equal t the earlier sphere stays
             b.t = t;
             b.pos = pos;
-            b.far = far;
         }
     }
 }
@@ -322,8 +320,10 @@ struct Walk {
     float c[3];        // current cell (small integers, exact in f32)
     uint32_t e, e_end; // entries of the current cell still to test
     // Closest accepted root so far as one ordered key: bits of t (positive floats order like integers) in the high
-    // word, then the sphere's position in the caller's list and the far-root flag.  The minimum key is the scalar
-    // scan's answer: smallest t, on equal t the sphere inserted first (hittable_list.rs:65-70).
+    // word, the sphere's position in the caller's list in the low one.  The minimum key is the scalar scan's
+    // answer: smallest t, on equal t the sphere inserted first (hittable_list.rs:65-70).  (Which of its two roots
+    // the winner was accepted with is not kept: the winner is evaluated again before shading, and every select
+    // spared here is spared eight times a segment.)
     unsigned long long best;
 };
 
@@ -341,8 +341,7 @@ __device__ __forceinline__ void walk_test(Walk& w, const V4 s, int32_t pos, cons
     const bool far = !(t0 > ray.tmin);
     const float t = far ? h + sq : t0;
     const bool valid = t > ray.tmin; // t > tmin > 0: its bits order like an unsigned integer
-    const unsigned long long key =
-        ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)(((uint32_t)pos << 1) | (far ? 1u : 0u));
+    const unsigned long long key = ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)(uint32_t)pos;
     w.best = (valid & (key < w.best)) ? key : w.best;
 }
 
@@ -653,7 +652,7 @@ __device__ __forceinline__ void render_f32_body() {
     bool fresh = false;   // the ray has not been intersected yet
     bool camera = false;  // a sample has been taken and its camera ray is still to be made
     bool walking = false; // grid scan: the lane is on its way through the grid
-    ScanBest sb = {INFINITY, -1, false};
+    ScanBest sb = {INFINITY, -1};
     Walk walk = {};
     float box_t = INFINITY; // BOXES: distance of the closest box along the lane's ray, and the box's list position
     int32_t box_idx = -1;
@@ -733,7 +732,7 @@ __device__ __forceinline__ void render_f32_body() {
             }
             PathRay nray = ray;
             nray.tmin = fmaxf(ray.tmin, 0.f);
-            sb = {INFINITY, -1, false};
+            sb = {INFINITY, -1};
             if constexpr (SCAN == kScanHybrid)
                 scan_hybrid(lds_xy, as_constant(a->filter_zn), as_constant(a->narrow_geom), a->n_narrow_padded, nray, sb);
             else if constexpr (SCAN == kScanGrid)
@@ -787,10 +786,8 @@ __device__ __forceinline__ void render_f32_body() {
         V4 m = {0.f, 0.f, 0.f, 0.f};
         if (shading) {
             if constexpr (SCAN == kScanGrid) {
-                const uint32_t low = (uint32_t)walk.best;
                 sb.t = __uint_as_float((uint32_t)(walk.best >> 32));
-                sb.pos = walk.best == kNoHit ? -1 : (int32_t)(low >> 1);
-                sb.far = (low & 1u) != 0u;
+                sb.pos = (int32_t)(uint32_t)walk.best; // (no hit: all ones, -1)
             }
             const float ox = ray.o.x, oy = ray.o.y, oz = ray.o.z, dx = ray.d.x, dy = ray.d.y, dz = ray.d.z;
             const float tmin = ray.tmin;
@@ -805,7 +802,8 @@ __device__ __forceinline__ void render_f32_body() {
                 const F3 l = {fmaf(-h, dx, oc.x), fmaf(-h, dy, oc.y), fmaf(-h, dz, oc.z)};
                 const float disc = fmaxf(fmaf(s.w, s.w, -dot(l, l)), 0.f);
                 const float sq = fsqrt(disc);
-                best = sb.far ? h + sq : h - sq;
+                best = h - sq; // sphere.rs:38-44
+                if (!(best > tmin)) best = h + sq;
                 hp = {fmaf(best, dx, ox), fmaf(best, dy, oy), fmaf(best, dz, oz)};
                 const float ir = rcp(s.w);
                 hn = {(hp.x - s.x) * ir, (hp.y - s.y) * ir, (hp.z - s.z) * ir}; // sphere.rs:52
@@ -1213,14 +1211,14 @@ __global__ __launch_bounds__(256) void path_step_f32_kernel(StepArgs) {
             int32_t bidx = -1;
             F3 hp = {0.f, 0.f, 0.f}, hn = {0.f, 0.f, 0.f};
             if (walk.best != kNoHit) {
-                const uint32_t low = (uint32_t)walk.best;
-                bidx = (int32_t)(low >> 1);
+                bidx = (int32_t)(uint32_t)walk.best;
                 const V4 s = a->geom32[bidx];
                 const F3 oc = {s.x - ox, s.y - oy, s.z - oz};
                 const float h = dot(oc, ray.d);
                 const F3 l = {fmaf(-h, dx, oc.x), fmaf(-h, dy, oc.y), fmaf(-h, dz, oc.z)};
                 const float sq = fsqrt(fmaxf(fmaf(s.w, s.w, -dot(l, l)), 0.f));
-                best = (low & 1u) ? h + sq : h - sq;
+                best = h - sq; // sphere.rs:38-44
+                if (!(best > tmin)) best = h + sq;
                 hp = {fmaf(best, dx, ox), fmaf(best, dy, oy), fmaf(best, dz, oz)};
                 const float ir = rcp(s.w);
                 hn = {(hp.x - s.x) * ir, (hp.y - s.y) * ir, (hp.z - s.z) * ir}; // sphere.rs:52

@@ -30,6 +30,12 @@ constexpr int ITERS = 2048;
 #define ADD64(r) "v_add_f64 " #r ", " #r ", %8\n"
 #define MAD64(r) "v_mad_u64_u32 " #r ", vcc, %9, v1, " #r "\n"
 #define RCP64(r) "v_rcp_f64 " #r ", " #r "\n"
+#define MAD64V(r) "v_mad_u64_u32 " #r ", vcc, v2, v1, " #r "\n"
+#define XOR_S(r) "v_xor_b32 " #r ", %9, " #r "\n"
+#define XOR_V(r) "v_xor_b32 " #r ", %8, " #r "\n"
+#define MULHI(r) "v_mul_hi_u32 " #r ", %8, " #r "\n"
+#define LSHLADD_S(r) "v_lshl_add_u32 " #r ", " #r ", 2, %9\n"
+#define CMPU64(r) "v_cmp_lt_u64_e32 vcc, " #r ", %8\n"
 
 template <int WHICH>
 __global__ __launch_bounds__(256) void k(float* out, float sb, float c) {
@@ -57,6 +63,12 @@ __global__ __launch_bounds__(256) void k(float* out, float sb, float c) {
         if (WHICH == 16) OP8D(ADD64);
         if (WHICH == 17) OP8D(MAD64);
         if (WHICH == 18) OP8D(RCP64);
+        if (WHICH == 19) OP8D(MAD64V);
+        if (WHICH == 20) OP8(XOR_S);
+        if (WHICH == 21) OP8(XOR_V);
+        if (WHICH == 22) OP8(MULHI);
+        if (WHICH == 23) OP8(LSHLADD_S);
+        if (WHICH == 24) OP8D(CMPU64);
     }
     out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + (float)(d0 + d1 + d2 + d3 + d4 + d5 + d6 + d7);
 }
@@ -87,7 +99,7 @@ int main() {
     float* d_out;
     CHECK(hipMalloc(&d_out, sizeof(float) * 256 * p.multiProcessorCount * 8));
     const int cus = p.multiProcessorCount;
-    for (int per_cu : {6, 4, 1}) {
+    for (int per_cu : {6, 1}) {
 #define RUN(name, which, n) if (run(name, k<which>, d_out, cus, per_cu, n)) return 1
         RUN("v_sub_f32 v,v,v", 0, 1);
         RUN("v_cndmask vcc", 1, 1);
@@ -108,6 +120,12 @@ int main() {
         RUN("v_add_f64", 16, 1);
         RUN("v_mad_u64_u32 (s operand)", 17, 1);
         RUN("v_rcp_f64", 18, 1);
+        RUN("v_mad_u64_u32 (v operands)", 19, 1);
+        RUN("v_xor_b32 s operand", 20, 1);
+        RUN("v_xor_b32 v operands", 21, 1);
+        RUN("v_mul_hi_u32", 22, 1);
+        RUN("v_lshl_add_u32 s operand", 23, 1);
+        RUN("v_cmp_lt_u64 -> vcc", 24, 1);
     }
     CHECK(hipFree(d_out));
     return 0;
