@@ -12,7 +12,7 @@ tools/config_records.sh 2 4 5 || exit 1
 timeout -k 10 200 python3 tools/context_timing.py > $out/context_timing.json || exit 1
 timeout -k 10 200 python3 tools/rank_overhead.py > $out/rank_overhead.jsonl || exit 1
 timeout -k 10 200 python3 tools/independent_seed_psnr.py > $out/independent_seed_psnr.json || exit 1
-timeout -k 10 200 python3 tools/path_step_bench.py --modes f64 > $out/path_step_bench.jsonl || exit 1
+timeout -k 10 200 python3 tools/path_step_bench.py > $out/path_step_bench.jsonl || exit 1
 timeout -k 10 200 python3 tools/fullsize_parity.py > $out/fullsize_parity.txt || exit 1
 DRAY_BENCH_REHEARSAL=1 timeout -k 10 300 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29577 bench.py --gpus 2 --steps 2 --warmup 1 --no-cpu-baseline --verify-image > $out/rehearsal_2ranks_fullsize.json 2> $out/rehearsal_err.txt || { tail -5 $out/rehearsal_err.txt; exit 1; }
 if [ -f tools/ab_libs/sections.so ]; then
