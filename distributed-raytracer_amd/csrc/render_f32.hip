@@ -438,8 +438,11 @@ __device__ __forceinline__ bool walk_step(const GridRegs& g, const PathRay& ray,
         w.c[0] += sx ? copysignf(1.f, w.A[0]) : 0.f;
         w.c[1] += sy ? copysignf(1.f, w.A[1]) : 0.f;
         w.c[2] += (sx | sy) ? 0.f : copysignf(1.f, w.A[2]);
-        const float moved = sx ? w.c[0] : (sy ? w.c[1] : w.c[2]), limit = sx ? g.n0 : (sy ? g.n1 : g.n2);
-        const bool inside = (moved >= 0.f) & (moved < limit);
+        // still inside the grid: a coordinate is a whole number from -1 to n, and as unsigned integers the bits of -1
+        // lie above those of every count (three compares; picking the axis that moved and its count costs four selects)
+        const bool in0 = __float_as_uint(w.c[0]) < __float_as_uint(g.n0), in1 = __float_as_uint(w.c[1]) < __float_as_uint(g.n1);
+        const bool in2 = __float_as_uint(w.c[2]) < __float_as_uint(g.n2);
+        const bool inside = in0 & in1 & in2;
         go = inside & !stop;
         const uint32_t ci = (uint32_t)fmaf(fmaf(w.c[2], g.n1, w.c[1]), g.n0, w.c[0]);
         const uint2 rec = g.cells[go ? ci : 0u];
@@ -468,8 +471,11 @@ __device__ __forceinline__ bool walk_step(const GridLds& g, const PathRay& ray, 
         w.c[0] += sx ? copysignf(1.f, w.A[0]) : 0.f;
         w.c[1] += sy ? copysignf(1.f, w.A[1]) : 0.f;
         w.c[2] += (sx | sy) ? 0.f : copysignf(1.f, w.A[2]);
-        const float moved = sx ? w.c[0] : (sy ? w.c[1] : w.c[2]), limit = sx ? g.n0 : (sy ? g.n1 : g.n2);
-        const bool inside = (moved >= 0.f) & (moved < limit);
+        // still inside the grid: a coordinate is a whole number from -1 to n, and as unsigned integers the bits of -1
+        // lie above those of every count (three compares; picking the axis that moved and its count costs four selects)
+        const bool in0 = __float_as_uint(w.c[0]) < __float_as_uint(g.n0), in1 = __float_as_uint(w.c[1]) < __float_as_uint(g.n1);
+        const bool in2 = __float_as_uint(w.c[2]) < __float_as_uint(g.n2);
+        const bool inside = in0 & in1 & in2;
         go = inside & !stop;
         const uint32_t ci = (uint32_t)fmaf(fmaf(w.c[2], g.n1, w.c[1]), g.n0, w.c[0]);
         const uint32_t rec = g.cells[go ? ci : 0u];
