@@ -513,8 +513,11 @@ void render_f64_stream_kernel(F64Args) {
                         wk.c[0] += sx ? copysignf(1.f, wA[0]) : 0.f;
                         wk.c[1] += sy ? copysignf(1.f, wA[1]) : 0.f;
                         wk.c[2] += (sx | sy) ? 0.f : copysignf(1.f, wA[2]);
-                        const float moved = sx ? wk.c[0] : (sy ? wk.c[1] : wk.c[2]), limit = sx ? gn0 : (sy ? gn1 : gn2);
-                        const bool inside = (moved >= 0.f) & (moved < limit);
+                        // still inside the grid: a coordinate is a whole number from -1 to n, and as unsigned integers the
+                        // bits of -1 lie above those of every count (three compares instead of four selects and two)
+                        const bool in0 = __float_as_uint(wk.c[0]) < __float_as_uint(gn0), in1 = __float_as_uint(wk.c[1]) < __float_as_uint(gn1);
+                        const bool in2 = __float_as_uint(wk.c[2]) < __float_as_uint(gn2);
+                        const bool inside = in0 & in1 & in2;
                         const bool go = inside & !stop;
                         walking = go;
                         const uint32_t ci = (uint32_t)fmaf(fmaf(wk.c[2], gn1, wk.c[1]), gn0, wk.c[0]);
