@@ -833,11 +833,10 @@ __device__ __forceinline__ void render_f32_body() {
                     const float disc = fmaf(h, h, -c);
                     if (disc >= 0.f) {
                         const float sq = fsqrt(disc);
-                        const bool up = h >= 0.f;
-                        const float big = up ? h + sq : h - sq;
-                        const float small = c * rcp(big); // (big = 0 only with c = 0: NaN, which fails the comparisons below)
-                        float t = up ? small : big;       // the near root
-                        if (!(t > tmin)) t = up ? big : small;
+                        const float big = h + copysignf(sq, h); // the root that is a sum
+                        const float small = c * rcp(big);       // (big = 0 only with c = 0: NaN, which fails the comparisons below)
+                        float t = fminf(big, small);            // the near root: the sum if h < 0, the quotient otherwise
+                        if (!(t > tmin)) t = fmaxf(big, small);
                         if (t > tmin && (t < best || (t == best && idx < bidx))) {
                             best = t;
                             bidx = idx;
