@@ -116,42 +116,43 @@ __device__ __forceinline__ float rsq(float x) { return __builtin_amdgcn_rsqf(x);
 __device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 
+// The rejection samplers' attempts.  A coordinate is -1 + 2 u, u = k 2^-24 (prelude.rs:27-30).
+__device__ __forceinline__ float attempt_coord(uint32_t w) { return fmaf(2.f, u01<float>(w), -1.f); }
+// vec3.rs:80, 1e-160 <= |p|^2 <= 1 in f32 terms: 0 < l2 <= 1 (a sum of squares of multiples of 2^-23 is 0 or at least
+// 2^-46), which for a value that is not negative is one unsigned compare of its bits.
+__device__ __forceinline__ bool vector_kept(float l2) { return __float_as_uint(l2) - 1u < 0x3F800000u; }
 // vec3.rs:76-84: rejection sampling in the cube; attempt a = words 0..2 of block a of the stage.
 __device__ __forceinline__ bool unit_vector_attempt(const uint32_t (&w)[4], F3& out) {
-    const F3 p = {fmaf(2.f, u01<float>(w[0]), -1.f), fmaf(2.f, u01<float>(w[1]), -1.f), fmaf(2.f, u01<float>(w[2]), -1.f)};
+    const F3 p = {attempt_coord(w[0]), attempt_coord(w[1]), attempt_coord(w[2])};
     const float l2 = dot(p, p);
     out = p * rsq(l2);
-    return (1e-30f <= l2) & (l2 <= 1.f);
-}
-
-// vec3.rs:111-118: rejection sampling in the square; an aperture attempt is two consecutive uniforms.
-__device__ __forceinline__ bool unit_disk_attempt(uint32_t wx, uint32_t wy, float& px, float& py) {
-    px = fmaf(2.f, u01<float>(wx), -1.f);
-    py = fmaf(2.f, u01<float>(wy), -1.f);
-    return fmaf(px, px, py * py) < 1.f;
+    return vector_kept(l2);
 }
 
 enum { kDrawNone = 0, kDrawUnitVector = 1, kDrawUnitDisk = 2 };
 
 // The two rejection samplers of the path for all lanes of a wave at once.  Called by all 64 lanes (wave-uniform
 // control flow).  `draw` says what the lane needs: a unit vector for its scatter (attempt a = words 0..2 of block a
-// of its stage), a point in the unit disk for its new sample's aperture (attempt m = uniforms 2+2m, 3+2m of stage
-// 0, i.e. the second half of block 0, then two attempts per block), or nothing.  `w` holds block 0 of the lane's
-// stream.  A unit-vector attempt succeeds with probability pi/6, so run lane by lane the wave would spend the
-// MAXIMUM attempt count over its lanes (about six Philox blocks) with most lanes idle.  Instead, after every
+// of its stage), a point in the unit disk for its new sample's aperture (vec3.rs:111-118; attempt m = uniforms 2+2m,
+// 3+2m of stage 0, i.e. the second half of block 0, then two attempts per block), or nothing.  `w` holds block 0 of
+// the lane's stream.  A unit-vector attempt succeeds with probability pi/6, so run lane by lane the wave would spend
+// the MAXIMUM attempt count over its lanes (about six Philox blocks) with most lanes idle.  Instead, after every
 // lane's own first attempt, the lanes still pending hand their stream to k = 1, 2, 4 or 8 server lanes each
 // (k * pending <= 64), which evaluate the next k blocks in parallel; the pending lane takes the accepted attempt
 // with the smallest index.  Same streams, same attempts, same winner as the sequential loops -- in about three
-// rounds.  Requests travel through the wave's `req` slots in LDS (LDS keeps one wave's accesses in order),
-// results through lane permutes.  Returns the unit vector, or the disk point in x, y.
+// rounds.  Requests travel through the wave's `req` slots in LDS (LDS keeps one wave's accesses in order), the kept
+// attempt's coordinates come back through lane permutes, and only the kept attempt is normalised (vec3.rs:82).
+// Returns the unit vector, or the disk point in x, y.
 __device__ __forceinline__ F3 coop_draw(const Stream& st, const uint32_t (&w)[4], uint32_t draw, uint4* req, int lane,
                                         uint32_t* rounds = nullptr) {
-    F3 res = {0.f, 0.f, 0.f};
+    float rx = attempt_coord(w[0]), ry = attempt_coord(w[1]), rz = attempt_coord(w[2]); // the kept attempt
     bool pending = false;
     if (draw == kDrawUnitVector) {
-        pending = !unit_vector_attempt(w, res);
-    } else if (draw == kDrawUnitDisk) {
-        pending = !unit_disk_attempt(w[2], w[3], res.x, res.y);
+        pending = !vector_kept(fmaf(rz, rz, fmaf(ry, ry, rx * rx)));
+    } else if (draw == kDrawUnitDisk) { // attempt 0 of the aperture sample: uniforms 2, 3 of stage 0
+        rx = rz;
+        ry = attempt_coord(w[3]);
+        pending = !(fmaf(rx, rx, ry * ry) < 1.f);
     }
     uint32_t base = 1u; // next block index, the same for every pending lane
     for (unsigned long long pm = __ballot(pending); pm != 0ull; pm = __ballot(pending)) {
@@ -161,29 +162,37 @@ __device__ __forceinline__ F3 coop_draw(const Stream& st, const uint32_t (&w)[4]
         if (pending) req[rank] = make_uint4(st.pixel, st.sample, st.stage, draw);
         const uint32_t served = (uint32_t)lane >> shift; // rank of the pending lane this lane serves
         const bool serving = served < n_pending;
-        const uint4 r = req[serving ? served : 0u];
+        const uint4 r = req[served]; // (a lane that serves nobody reads a slot of 64 that nobody wrote: its verdict is not looked at)
         const Stream other = {st.k0, st.k1, r.x, r.y, r.z};
         uint32_t wb[4];
         other.block(base + ((uint32_t)lane & ((1u << shift) - 1u)), wb);
-        F3 v;
-        const bool ok_vector = unit_vector_attempt(wb, v);
-        float ax, ay, bx, by;
-        const bool ok_a = unit_disk_attempt(wb[0], wb[1], ax, ay), ok_b = unit_disk_attempt(wb[2], wb[3], bx, by);
+        // one unit-vector attempt (words 0..2), or two aperture attempts (words 0, 1 and 2, 3): the same four coordinates
+        const float px = attempt_coord(wb[0]), py = attempt_coord(wb[1]), pz = attempt_coord(wb[2]), pq = attempt_coord(wb[3]);
+        const bool ok_vector = vector_kept(fmaf(pz, pz, fmaf(py, py, px * px)));
+        const bool ok_a = fmaf(px, px, py * py) < 1.f, ok_b = fmaf(pz, pz, pq * pq) < 1.f;
         const bool disk = r.w == kDrawUnitDisk;
-        if (disk) v = {ok_a ? ax : bx, ok_a ? ay : by, 0.f};
+        const bool second = disk & !ok_a; // the aperture's second attempt of the block is the one to hand back
+        const float vx = second ? pz : px, vy = second ? pq : py;
         const bool ok = serving & (disk ? (ok_a | ok_b) : ok_vector);
         const unsigned long long okm = __ballot(ok);
         const uint32_t first = pending ? (rank << shift) : 0u; // my first server lane (< 64; a lane that is not pending has none)
         const uint32_t mine = (uint32_t)(okm >> first) & ((1u << (1u << shift)) - 1u); // my servers' verdicts
         const bool got = pending & (mine != 0u);
         const int from = got ? (int)(first + (uint32_t)__builtin_ctz(mine)) : lane;
-        const float vx = __shfl(v.x, from, 64), vy = __shfl(v.y, from, 64), vz = __shfl(v.z, from, 64);
+        const float gx = __shfl(vx, from, 64), gy = __shfl(vy, from, 64), gz = __shfl(pz, from, 64);
         if (got) {
-            res = {vx, vy, vz};
+            rx = gx;
+            ry = gy;
+            rz = gz;
             pending = false;
         }
         base += 1u << shift;
         if (rounds) ++*rounds;
+    }
+    F3 res = {rx, ry, 0.f};
+    if (draw == kDrawUnitVector) {
+        const F3 p = {rx, ry, rz};
+        res = p * rsq(dot(p, p));
     }
     return res;
 }
