@@ -1189,6 +1189,52 @@ def test_path_step_f32_close_to_oracle(dray, gpu, oracle):
     assert abs(segments - ost.segments) <= 0.003 * ost.segments
 
 
+def test_path_step_rays_parallel_to_the_grid_planes(dray, gpu, oracle):
+    """Rays whose direction has one or two components that are exactly zero -- parallel to planes of the grid, which no
+    camera or scatter produces but a caller of dray_path_step may hand over -- from origins inside and outside the
+    grid's box, with directions that are not unit vectors: the f64 step equals the oracle's bytes (hittable_list.rs:60-74
+    over the whole list), and the f32 step, whose walk sets such an axis up with a clamped reciprocal, agrees with it on
+    what is hit wherever the hit is not a grazing one."""
+    rng = np.random.default_rng(21)
+    for spheres, span in ((dray.scene_final(1), 12.0), (dray.scene_grid_10k(1), 52.0)):
+        cam = dray.camera_final(width=64, spp=1, depth=50)
+        cam.seed = 4
+        W = cam.image_width
+        n = 6000
+        px = np.stack([rng.integers(0, W, n), rng.integers(0, cam.initialize().image_height, n), np.zeros(n, int)], axis=1).astype(np.int32)
+        cam.mode = dray.MODE_F64
+        e = gpu.camera_rays(cam, px)
+        axes = rng.integers(0, 3, n)
+        d = rng.normal(0, 1, (n, 3)) * rng.choice([0.5, 1.0, 3.0], (n, 1))
+        d[np.arange(n), axes] = 0.0                              # one component zero ...
+        two = rng.random(n) < 0.4
+        d[two, (axes[two] + 1) % 3] = 0.0                        # ... or two: along an axis
+        d[rng.random(n) < 0.1] *= -1.0
+        o = rng.uniform(-1.2 * span, 1.2 * span, (n, 3))
+        o[:, 1] = rng.choice([0.2, 0.05, 0.39, 1.0, 3.0, -0.5], n) + rng.normal(0, 1e-3, n)
+        low = rng.random(n) < 0.5                                # half of them skim the layer of small spheres
+        d[low & (axes != 1), 1] *= 0.02
+        e["origin"], e["direction"] = o, d
+        oe, e32 = e.copy(), e.copy()
+        scene = gpu.DeviceScene(spheres, 0)
+        gpu.ray_color_iteration(e, scene, cam)
+        oracle.ray_color_iteration(oe, spheres, W, seed=4)
+        assert e.tobytes() == oe.tobytes()
+        cam.mode = dray.MODE_F32
+        gpu.ray_color_iteration(e32, scene, cam)
+        scene.close()
+        hit64 = (e["finished"] == 0)
+        hit32 = (e32["finished"] == 0)
+        assert hit64.sum() > n // 20
+        same = hit64 == hit32
+        # (a Lambertian or Metal bounce leaves from the hit point: where both went on, the points agree to f32 rounding)
+        both = hit64 & hit32
+        close = np.abs(e["origin"][both] - e32["origin"][both]).max(axis=1) < 2e-3 * (1.0 + np.abs(e["origin"][both]).max(axis=1))
+        report("path_step_parallel_rays_%d" % len(spheres), rays=n, hit=int(hit64.sum()), same_verdict=float(same.mean()),
+               same_point=float(close.mean()))
+        assert same.mean() >= 0.999 and close.mean() >= 0.995
+
+
 def test_bench_two_ranks_rehearsal(dray, gpu):
     """bench.py the way the driver launches it for N > 1 (torch.distributed.run, one process per rank), rehearsed
     with two ranks on this box's one GPU: DRAY_BENCH_REHEARSAL=1 swaps RCCL (which refuses two ranks on a device) for
