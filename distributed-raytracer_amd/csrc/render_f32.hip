@@ -827,7 +827,7 @@ __device__ __forceinline__ void render_f32_body() {
             ConstPtr<int32_t> wide_index = as_constant(a->wide_index);
             ConstPtr<double> geom64 = as_constant(a->wide_geom64); // the wide spheres' rows, side by side
             ConstPtr<V4> wide_axial = as_constant(a->wide_axial);
-            for (int32_t wq = 0; wq < n_wide; ++wq) {
+            auto wide_sphere = [&](int32_t wq) {
 #ifndef DRAY_NO_AXIAL
                 if (wide_axial[2 * wq + 1].z != 0.f) {
                     // A wide sphere whose centre lies by the y axis (the ground, src/main.rs:14), sphere.rs:28-57 in f32 without
@@ -853,7 +853,7 @@ __device__ __forceinline__ void render_f32_body() {
                             hn = {(hp.x - g.x) * g.w, (hp.y - g.y) * g.w, (hp.z - g.z) * g.w}; // sphere.rs:52
                         }
                     }
-                    continue;
+                    return;
                 }
 #endif
                 // sphere.rs:28-57 in f64 for a sphere too large for f32: the cancelling terms (oc, |oc|^2 - r^2,
@@ -885,7 +885,10 @@ __device__ __forceinline__ void render_f32_body() {
                         hn = {(float)(px - cx) * ir, (float)(py - cy) * ir, (float)(pz - cz) * ir}; // sphere.rs:52
                     }
                 }
-            }
+            };
+            // (one wide sphere, the usual case, is straight-line code: a loop carries best, point and normal through copies)
+            if (n_wide == 1) wide_sphere(0);
+            else for (int32_t wq = 0; wq < n_wide; ++wq) wide_sphere(wq);
             if constexpr (BOXES) {
                 // a box in front of the closest sphere (on equal distance: earlier in the list) is what the ray hits; its
                 // material, Transparent, makes the sample black (its kind in this kernel's table is the absorber's)
