@@ -929,11 +929,51 @@ __device__ __forceinline__ void render_f32_body() {
         DRAY_COUNT(6, want != 0ull ? 1 : 0);                       // iterations that refill
         // compaction switched off: the wave refills only as a whole, once its last path has ended
         if (a->no_refill != 0 && __ballot(stage > 0) != 0ull) want = 0ull;
+        {
+        const uint32_t W = (uint32_t)a->cam.W, spp = (uint32_t)a->cam.spp;
+        // a hand-out of at most 64 samples crosses at most 64 / spp pixels (stepped over one by one, cheaper than
+        // two integer divisions per lane down to 8 samples per pixel) and, with rows longer than a pool, one row end
+        const bool stepwise = spp >= 8u && W >= (uint32_t)kSlots;
+        // hands the open pool's next samples to the lanes that want one; returns the lanes still wanting
+        auto hand_out = [&](unsigned long long want) -> unsigned long long {
+            const uint32_t avail = pool_n - pool_q;
+            const uint32_t wanted = (uint32_t)__popcll(want);
+            const uint32_t take = wanted < avail ? wanted : avail;
+            const uint32_t rank = (uint32_t)__popcll(want & ((1ull << lane) - 1ull));
+            if (need && rank < take) {
+                // the lane's place in the pool: pixel `dp` places after the pool's first, sample `smp` of it
+                uint32_t dp, smp, r, i;
+                if (stepwise) { // a few conditional steps instead of two integer divisions per hand-out
+                    smp = pool_smp + rank;
+                    dp = pool_dp;
+                    while (smp >= spp) { smp -= spp; dp++; }
+                    i = pool_i0 + dp;
+                    r = pool_r0;
+                    if (i >= W) { i -= W; r++; }
+                } else {
+                    const uint32_t q = pool_q + rank;
+                    dp = q / spp;
+                    smp = q - dp * spp;
+                    const uint32_t pix = pool_pix + dp;
+                    r = pix / W;
+                    i = pix - r * W;
+                }
+                const int32_t pi = (int32_t)i, pj = a->part.row_begin + (int32_t)r * a->part.row_step;
+                gpix = (uint32_t)pj * W + (uint32_t)pi;
+                ss = smp | (((pool_slot + dp) & (uint32_t)(kSlots - 1)) << 24);
+                ray.o = {(float)pi, (float)pj, 0.f}; // exact; the camera step below turns them into the ray
+                camera = true;
+                need = false;
+            }
+            pool_q += take;
+            pool_smp += take;
+            while (pool_smp >= spp) { pool_smp -= spp; pool_dp++; } // only read when stepwise
+            return __ballot(need);
+        };
+        // the usual turn -- the open pool has samples left -- is straight-line code: the loop below, which may open
+        // pools, carries every lane's new pixel, sample and ray origin through copies
+        if (want != 0ull && pool_q != pool_n) want = hand_out(want);
         while (want != 0ull) {
-            const uint32_t W = (uint32_t)a->cam.W, spp = (uint32_t)a->cam.spp;
-            // a hand-out of at most 64 samples crosses at most 64 / spp pixels (stepped over one by one, cheaper than
-            // two integer divisions per lane down to 8 samples per pixel) and, with rows longer than a pool, one row end
-            const bool stepwise = spp >= 8u && W >= (uint32_t)kSlots;
             if (pool_q == pool_n && !exhausted) { // open the next pool
                 const uint32_t npix = pixel_count(), pixels_per_pool = (uint32_t)a->pixels_per_pool;
                 if (grab_next == grab_end) {
@@ -973,39 +1013,8 @@ __device__ __forceinline__ void render_f32_body() {
                 if (need) stage = -1;
                 break;
             }
-            const uint32_t avail = pool_n - pool_q;
-            const uint32_t wanted = (uint32_t)__popcll(want);
-            const uint32_t take = wanted < avail ? wanted : avail;
-            const uint32_t rank = (uint32_t)__popcll(want & ((1ull << lane) - 1ull));
-            if (need && rank < take) {
-                // the lane's place in the pool: pixel `dp` places after the pool's first, sample `smp` of it
-                uint32_t dp, smp, r, i;
-                if (stepwise) { // a few conditional steps instead of two integer divisions per hand-out
-                    smp = pool_smp + rank;
-                    dp = pool_dp;
-                    while (smp >= spp) { smp -= spp; dp++; }
-                    i = pool_i0 + dp;
-                    r = pool_r0;
-                    if (i >= W) { i -= W; r++; }
-                } else {
-                    const uint32_t q = pool_q + rank;
-                    dp = q / spp;
-                    smp = q - dp * spp;
-                    const uint32_t pix = pool_pix + dp;
-                    r = pix / W;
-                    i = pix - r * W;
-                }
-                const int32_t pi = (int32_t)i, pj = a->part.row_begin + (int32_t)r * a->part.row_step;
-                gpix = (uint32_t)pj * W + (uint32_t)pi;
-                ss = smp | (((pool_slot + dp) & (uint32_t)(kSlots - 1)) << 24);
-                ray.o = {(float)pi, (float)pj, 0.f}; // exact; the camera step below turns them into the ray
-                camera = true;
-                need = false;
-            }
-            pool_q += take;
-            pool_smp += take;
-            while (pool_smp >= spp) { pool_smp -= spp; pool_dp++; } // only read when stepwise
-            want = __ballot(need);
+            want = hand_out(want);
+        }
         }
         if (__ballot(stage > 0 || camera) == 0ull) break;
 
