@@ -689,7 +689,37 @@ void render_f64_stream_kernel(F64Args) {
         {
             bool need = !has;
             unsigned long long want = __ballot(need);
-            while (want != 0ull) {
+            // hands the next samples of the open chunk to the lanes that want one; returns the lanes still wanting
+            // (`none`: there was no sample or no room in the ring to hand out)
+            auto hand_out = [&](unsigned long long want, bool& none) -> unsigned long long {
+                const uint32_t room = kF64RingEntries - (issued - retired); // a ring's length ahead of the oldest at most
+                const uint32_t avail = min(iss_left, room);
+                const uint32_t wanted = (uint32_t)__popcll(want);
+                const uint32_t take = wanted < avail ? wanted : avail;
+                none = take == 0u;
+                if (none) return want;
+                const uint32_t rank = (uint32_t)__popcll(want & ((1ull << lane) - 1ull));
+                if (need && rank < take) {
+                    const uint32_t q = iss_q + rank;
+                    const uint32_t dp = q / spp;
+                    size_t out;
+                    place_of(iss_p0 + dp, out, pw);
+                    smp = q - dp * spp;
+                    item = issued + rank;
+                    has = true;
+                    camera = true;
+                    need = false;
+                }
+                iss_q += take;
+                iss_left -= take;
+                issued += take;
+                return __ballot(need);
+            };
+            // the usual turn -- the open chunk has samples left -- is straight-line code: the loop below, which may grab
+            // chunks, carries every lane's new sample through copies
+            bool none = false;
+            if (want != 0ull && iss_left != 0u) want = hand_out(want, none);
+            while (want != 0ull && !none) {
                 if (iss_left == 0u && !exhausted) { // the next chunk of pixels
                     if (grabbed - begun == kFifoSlots) break;
                     unsigned long long base = 0ull;
@@ -707,27 +737,7 @@ void render_f64_stream_kernel(F64Args) {
                     }
                 }
                 if (exhausted) break;
-                const uint32_t room = kF64RingEntries - (issued - retired); // a ring's length ahead of the oldest at most
-                const uint32_t avail = min(iss_left, room);
-                const uint32_t wanted = (uint32_t)__popcll(want);
-                const uint32_t take = wanted < avail ? wanted : avail;
-                if (take == 0u) break;
-                const uint32_t rank = (uint32_t)__popcll(want & ((1ull << lane) - 1ull));
-                if (need && rank < take) {
-                    const uint32_t q = iss_q + rank;
-                    const uint32_t dp = q / spp;
-                    size_t out;
-                    place_of(iss_p0 + dp, out, pw);
-                    smp = q - dp * spp;
-                    item = issued + rank;
-                    has = true;
-                    camera = true;
-                    need = false;
-                }
-                iss_q += take;
-                iss_left -= take;
-                issued += take;
-                want = __ballot(need);
+                want = hand_out(want, none);
             }
         }
         if (__ballot(has) == 0ull) {
