@@ -155,7 +155,8 @@ __device__ __forceinline__ F3 coop_draw(const Stream& st, const uint32_t (&w)[4]
         pending = !(fmaf(rx, rx, ry * ry) < 1.f);
     }
     uint32_t base = 1u; // next block index, the same for every pending lane
-    for (unsigned long long pm = __ballot(pending); pm != 0ull; pm = __ballot(pending)) {
+    // one round: the pending lanes `pm` are served blocks base .. base + k - 1 of their streams
+    auto round = [&](unsigned long long pm) {
         const uint32_t n_pending = (uint32_t)__popcll(pm);
         const uint32_t shift = n_pending <= 8u ? 3u : n_pending <= 16u ? 2u : n_pending <= 32u ? 1u : 0u; // log2 k
         const uint32_t rank = (uint32_t)__popcll(pm & ((1ull << lane) - 1ull));
@@ -188,6 +189,12 @@ __device__ __forceinline__ F3 coop_draw(const Stream& st, const uint32_t (&w)[4]
         }
         base += 1u << shift;
         if (rounds) ++*rounds;
+    };
+    // (the first round, which nearly every call needs, is straight-line code: a loop carries the kept attempt through copies)
+    unsigned long long pm = __ballot(pending);
+    if (pm != 0ull) {
+        round(pm);
+        for (pm = __ballot(pending); pm != 0ull; pm = __ballot(pending)) round(pm);
     }
     F3 res = {rx, ry, 0.f};
     if (draw == kDrawUnitVector) {
