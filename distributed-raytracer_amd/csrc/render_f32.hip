@@ -790,11 +790,15 @@ __device__ __forceinline__ void render_f32_body() {
             DRAY_CLOCK(0);
             DRAY_MARK("B_walk_steps");
             do { // two steps per count: the count is scalar-unit work every walking lane waits for
-                DRAY_COUNT(2, 2);                                  // walk steps (wave level)
-                DRAY_COUNT(3, 2 * __popcll(__ballot(walking)));    // lanes walking at those steps
-                if (walking) walking = walk_step(gr, nray, walk);
-                if (walking) walking = walk_step(gr, nray, walk);
-                n_steps += 2u;
+#ifndef DRAY_STEPS_PER_COUNT
+#define DRAY_STEPS_PER_COUNT 2
+#endif
+                DRAY_COUNT(2, DRAY_STEPS_PER_COUNT);                                  // walk steps (wave level)
+                DRAY_COUNT(3, DRAY_STEPS_PER_COUNT * __popcll(__ballot(walking)));    // lanes walking at those steps
+#pragma unroll
+                for (int step = 0; step < DRAY_STEPS_PER_COUNT; ++step)
+                    if (walking) walking = walk_step(gr, nray, walk);
+                n_steps += (uint32_t)DRAY_STEPS_PER_COUNT;
             } while (__popcll(__ballot(walking)) >= quorum);
         }
         DRAY_CLOCK(1);
