@@ -101,7 +101,8 @@ __device__ __forceinline__ Drawn coop_draw64(const Stream& st, const uint32_t (&
         }
     }
     uint32_t base = 1u; // next block index, the same for every pending lane
-    for (unsigned long long pm = __ballot(pending); pm != 0ull; pm = __ballot(pending)) {
+    // one round: the pending lanes `pm` are served blocks base .. base + k - 1 of their streams
+    auto round = [&](unsigned long long pm) {
         const uint32_t n_pending = (uint32_t)__popcll(pm);
         const uint32_t shift = n_pending <= 8u ? 3u : n_pending <= 16u ? 2u : n_pending <= 32u ? 1u : 0u; // log2 servers per lane
         const uint32_t rank = (uint32_t)__popcll(pm & ((1ull << lane) - 1ull));
@@ -137,6 +138,12 @@ __device__ __forceinline__ Drawn coop_draw64(const Stream& st, const uint32_t (&
             pending = false;
         }
         base += 1u << shift;
+    };
+    // (the first round, which nearly every call needs, is straight-line code: a loop carries the kept words through copies)
+    unsigned long long pm = __ballot(pending);
+    if (pm != 0ull) {
+        round(pm);
+        for (pm = __ballot(pending); pm != 0ull; pm = __ballot(pending)) round(pm);
     }
     return res;
 }
