@@ -884,7 +884,8 @@ void render_f64_stream_kernel(F64Args) {
                 if constexpr (iterative) {
                     c = vmul(att, c); // camera.rs:121,135,142
                 } else {
-                    while (sp > 0) { // camera.rs:274, innermost product first; four albedos are fetched at a time
+                    // camera.rs:274, innermost product first; four albedos are fetched at a time
+                    auto four = [&]() {
                         const int32_t n4 = sp < 4 ? sp : 4;
                         uint32_t q[4];
 #pragma unroll
@@ -896,6 +897,10 @@ void render_f64_stream_kernel(F64Args) {
                         for (int u = 0; u < 4; ++u)
                             if (u < n4) c = vmul(al[u], c);
                         sp -= n4;
+                    };
+                    if (sp > 0) { // (the first four, all that most samples have, without a loop's copies of the colour)
+                        four();
+                        while (sp > 0) four();
                     }
                 }
                 RingEntry* e = ring + (end_item & (kF64RingEntries - 1u));
