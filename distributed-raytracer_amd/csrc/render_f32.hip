@@ -194,7 +194,11 @@ __device__ __forceinline__ F3 coop_draw(const Stream& st, const uint32_t (&w)[4]
     unsigned long long pm = __ballot(pending);
     if (pm != 0ull) {
         round(pm);
-        for (pm = __ballot(pending); pm != 0ull; pm = __ballot(pending)) round(pm);
+        pm = __ballot(pending);
+        if (pm != 0ull) {
+            round(pm);
+            for (pm = __ballot(pending); pm != 0ull; pm = __ballot(pending)) round(pm);
+        }
     }
     F3 res = {rx, ry, 0.f};
     if (draw == kDrawUnitVector) {
