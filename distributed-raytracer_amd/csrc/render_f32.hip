@@ -28,6 +28,13 @@
 // cycles; f32 matrix instructions run on the same ALUs.  So the scan minimises VGPR-only ALU operations per
 // ray-sphere test and keeps the SGPR-sourced ones under ~60 % of the mix (scan_hybrid below: 8 operations, 3
 // of them SGPR-sourced, against 11 and 4 for the direct form of sphere.rs:29-36).
+//
+// Two more things the main loop is written around (tools/ubench_cost.hip): a compare or a select costs a SIMD 1.8 ns
+// where an addition costs 1.05 -- so bounds are arranged for NaN to fail a test by itself, roots are ordered with
+// min / max, whole-number coordinates are range-checked through their bits, and nothing is selected that the next
+// instruction does not need; and a loop that changes per-lane values under a condition carries a copy of each of them
+// round its edge -- so the case such a loop nearly always sees (one refill turn, one or two draw rounds, one wide
+// sphere) is written out in front of it.
 #include <cstdlib>
 #include <mutex>
 
