@@ -5,7 +5,7 @@ set -e
 name=$1; unit=$2; flags=$3
 cd "$(dirname "$0")/../distributed-raytracer_amd/csrc"
 mkdir -p ../../tools/ab_libs
-exact="-ffp-contract=off"; [ "$unit" = render_f32 ] && exact=""
+exact="-ffp-contract=off"; [ "$unit" = render_f32 ] && exact="-mllvm -phi-node-folding-threshold=0"   # (the Makefile's flags per file)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $exact $flags -c $unit.hip -o /tmp/variant_$name.o
 others=""
 for u in dray_api render_ref render_f64 render_f32; do [ $u = $unit ] || others="$others $u.o"; done

@@ -61,7 +61,7 @@ def main():
     unit = "render_f32" if args.kernel == "f32" else "render_f64"
     src = os.path.join(ROOT, "distributed-raytracer_amd", "csrc", unit + ".hip")
     with tempfile.TemporaryDirectory() as tmp:
-        exact = [] if args.kernel == "f32" else ["-ffp-contract=off"]
+        exact = ["-mllvm", "-phi-node-folding-threshold=0"] if args.kernel == "f32" else ["-ffp-contract=off"]  # the Makefile's flags per file
         subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-DDRAY_MARKS"] + exact +
                        ["-save-temps", "-c", src, "-o", os.path.join(tmp, "o.o")], cwd=tmp, check=True,
                        stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
